@@ -1,0 +1,123 @@
+/*
+ * mvlm_hip.h - C ABI of libmvlm_hip.so: the MI355X (gfx950) implementation of the
+ * cvjena/mvlm `Pipeline.predict_one_file` hot path.
+ *
+ * The reference is pure Python and has no FFI of its own; the interface each entry
+ * point replaces is the Python method cited next to it (paths relative to the
+ * reference's src/mvlm/).  INTEGRATION.md shows the ctypes binding a maintainer
+ * adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from mvlm_last_error(ctx).  Nothing throws across the boundary.
+ *   - "_dev" pointers are device (HBM) addresses owned by the caller (e.g. a torch
+ *     tensor's data_ptr()); "_host" pointers are ordinary host memory.  The library
+ *     never frees caller memory.
+ *   - all work is enqueued on the ctx's HIP stream (mvlm_set_stream; default: the
+ *     null stream).  Functions that return host results synchronise that stream.
+ *   - a ctx serialises its callers with an internal mutex (the reference server
+ *     calls predict_one_file from a thread pool without locks, 3DMD_server.py:26-31).
+ */
+#ifndef MVLM_HIP_H
+#define MVLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvlm_ctx mvlm_ctx;
+typedef struct mvlm_mesh mvlm_mesh;
+
+#define MVLM_IMAGE_SIZE 256          /* render3d.py / general_pipeline.py:57 */
+#define MVLM_CONV_DESC_INTS 12       /* ints per conv slot, see mvlm_amd/weights.py */
+
+enum { MVLM_MODE_QUANTILE = 0, MVLM_MODE_ABSOLUTE = 1 };   /* estimator3d.py:166-171 */
+enum { MVLM_MAXIMA_SIMPLE = 0, MVLM_MAXIMA_MOMENT = 1 };   /* paulsenpredictor.py:121,129 */
+
+/* ---- context ------------------------------------------------------------------ */
+int mvlm_ctx_create(int device, mvlm_ctx** out);
+void mvlm_ctx_destroy(mvlm_ctx* ctx);
+const char* mvlm_last_error(mvlm_ctx* ctx);
+int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream);
+int mvlm_synchronize(mvlm_ctx* ctx);
+/* name of the GPU architecture the library was built for ("gfx950") */
+const char* mvlm_build_arch(void);
+
+/* ---- mesh (replaces utils3d.py:10-85 obj_to_actor's upload half) ---------------- */
+/* verts f32[V,3], uvs f32[V,2] or NULL, tris i32[T,3], tex u8[H,W,3] (row 0 = top of
+ * the image file) or NULL (=> pure white mesh, utils3d.py:58-64).  Host pointers;
+ * the data is copied to the device. */
+int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                     const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
+                     mvlm_mesh** out);
+void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* mesh);
+
+/* ---- render (replaces render3d.py:114-177 + :191, all poses in one launch set) --- */
+/* rot_host f64[N,9]: row-major M = Ry*Rx*Rz per view (render3d.py:140-144).
+ * out_dev f32[N,256,256,4]: RGB + depth planes in [0,1], already flipped to
+ * image orientation (render3d.py:177) and divided by 255 (:191). */
+int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, int n_views, float* out_dev);
+
+/* ---- landmark network (replaces paulsenpredictor.py:89-110, :167-217) ------------ */
+/* blob/desc: output of mvlm_amd.weights.pack_for_device (BN folded, weights as
+ * [tap][cin_pad][cout_pad]); copied to the device. */
+int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_floats, const int32_t* desc_host, int n_slots,
+                  int n_landmarks, int in_channels);
+/* bytes of caller-provided device scratch needed to push `batch` views at once */
+size_t mvlm_cnn_workspace_bytes(mvlm_ctx* ctx, int batch);
+/* images_dev f32[N,256,256,4]; chan_sel_host int[in_channels] picks the planes fed to
+ * the net; maxima_dev f32[NL,N,3] = (row-1, col-0.5, value) per (landmark, view)
+ * (paulsenpredictor.py:123-127).  Views are processed `batch` at a time. */
+int mvlm_cnn_maxima(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
+                    float* maxima_dev, void* workspace_dev, size_t workspace_bytes, int batch);
+/* same network, but materialises the final-stage heatmaps f32[N,NL,256,256]
+ * (what paulsenpredictor.py:187-212 accumulates); used by tests and "moment" mode. */
+int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
+                      float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch);
+/* per-kernel timing of the last mvlm_cnn_* call when profiling is on: fills up to
+ * `cap` records of {slot, kernel_variant, flops, ms}; returns the record count. */
+int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled);
+int mvlm_cnn_get_profile(mvlm_ctx* ctx, int32_t* slot, int32_t* variant, double* flops, float* ms, int cap);
+const char* mvlm_conv_variant_name(int variant);
+
+/* heatmap maxima of materialised heatmaps (replaces paulsenpredictor.py:112-165).
+ * heat_dev f32[N,NL,S,S] -> out_dev f32[NL,N,3]. */
+int mvlm_heatmap_maxima(mvlm_ctx* ctx, const float* heat_dev, int n_views, int n_landmarks, int size, int method,
+                        float* out_dev);
+
+/* one generic convolution launch (the kernel the network is made of); test hook.
+ * x_dev f32[B,Cin,H,W] -> y_dev f32[B,Cout,H,W]; w_host f32[Cout,Cin,k,k] (k = 1|3,
+ * stride 1, pad k/2); optional bias / pre-BN+ReLU (scale,shift per Cin) / post-BN+ReLU
+ * (per Cout) / residual add r_dev f32[B,Cout,H,W]. */
+int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
+                int ksize, const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
+                const float* post_scale_host, const float* post_shift_host, const float* r_dev, int upsample_in,
+                float* y_dev);
+
+/* ---- rays + consensus (replaces estimator3d.py:31-90, :92-183, utils3d.py:99-124) - */
+/* maxima_dev f32[NL,N,3], rot_dev f64[N,9] -> starts_dev, ends_dev f64[NL,N,3] */
+int mvlm_estimate_lines(mvlm_ctx* ctx, const float* maxima_dev, const double* rot_dev, int n_views, int n_landmarks,
+                        int image_size, double* starts_dev, double* ends_dev);
+/* view filter (estimator3d.py:140-155): mask_dev u8[NL,N], count_dev i32[NL] */
+int mvlm_consensus_mask(mvlm_ctx* ctx, const float* maxima_dev, int n_views, int n_landmarks, int mode, double q,
+                        double thr, uint8_t* mask_dev, int32_t* count_dev);
+/* one wavefront per landmark: one-shot RANSAC + least squares (estimator3d.py:92-137,
+ * :173-181).  draws_dev i32[NL,8] = the host's np.random.choice draws (indices into the
+ * masked line list; ignored where count < 3).  out_dev f64[NL,3], err_dev f64[NL]
+ * (the landmark's contribution to sum_error; 0 where count < 3). */
+int mvlm_consensus_solve(mvlm_ctx* ctx, const double* starts_dev, const double* ends_dev, const uint8_t* mask_dev,
+                         const int32_t* count_dev, const int32_t* draws_dev, int n_views, int n_landmarks,
+                         double* out_dev, double* err_dev);
+
+/* ---- surface snap (replaces estimator3d.py:252-285) ------------------------------ */
+/* pts_dev f64[NL,3] -> out_dev f64[NL,3]: closest point on the triangle surface */
+int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* pts_dev, int n_points,
+                            double* out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVLM_HIP_H */

@@ -1,0 +1,141 @@
+"""ctypes binding of libmvlm_hip.so (the C ABI declared in include/mvlm_hip.h).
+
+There is no CPU fallback: if the library is missing or the GPU is not a gfx950
+the import of the product path fails loudly.  ``build()`` (re)compiles the
+library in-tree with hipcc (cross-compiles without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libmvlm_hip.so"
+CSRC = _HERE / "csrc"
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); mirrors include/mvlm_hip.h one to one
+SIGNATURES = {
+    "mvlm_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mvlm_ctx_destroy": (None, [C.c_void_p]),
+    "mvlm_last_error": (C.c_char_p, [C.c_void_p]),
+    "mvlm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mvlm_synchronize": (C.c_int, [C.c_void_p]),
+    "mvlm_build_arch": (C.c_char_p, []),
+    "mvlm_mesh_upload": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, c_int32_p, C.c_int, c_uint8_p,
+                                   C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mvlm_mesh_free": (None, [C.c_void_p, C.c_void_p]),
+    "mvlm_render": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_int, C.c_void_p]),
+    "mvlm_cnn_load": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_int32_p, C.c_int, C.c_int, C.c_int]),
+    "mvlm_cnn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "mvlm_cnn_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_int]),
+    "mvlm_cnn_heatmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_int]),
+    "mvlm_cnn_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mvlm_cnn_get_profile": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_float_p, C.c_int]),
+    "mvlm_conv_variant_name": (C.c_char_p, [C.c_int]),
+    "mvlm_heatmap_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mvlm_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int,
+                              c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvlm_estimate_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p]),
+    "mvlm_consensus_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_void_p, C.c_void_p]),
+    "mvlm_consensus_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
+    "mvlm_project_to_surface": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+class MvlmHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> Path:
+    """Compile libmvlm_hip.so for gfx950 with hipcc (mvlm_amd/csrc/Makefile)."""
+    if force and LIB_PATH.exists():
+        LIB_PATH.unlink()
+    jobs = str(min(8, os.cpu_count() or 1))
+    r = subprocess.run(["make", "-C", str(CSRC), "-j", jobs], capture_output=True, text=True)
+    if r.returncode != 0 or not LIB_PATH.exists():
+        raise MvlmHipError(f"building libmvlm_hip.so failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and attach the prototypes; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise MvlmHipError(
+            f"{LIB_PATH} not found - the MI355X HIP library is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C mvlm_amd/csrc`.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def as_ptr(arr, ctype):
+    """Host numpy array -> typed ctypes pointer (array must stay alive)."""
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class Context:
+    """One mvlm_ctx bound to a CUDA/HIP device index; owns nothing else."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self.handle = C.c_void_p()
+        rc = self.lib.mvlm_ctx_create(int(device), C.byref(self.handle))
+        if rc != 0:
+            reasons = {2: "no such GPU device", 3: "hipSetDevice failed", 4: "hipGetDeviceProperties failed",
+                       5: "device is not a gfx950 (MI355X)"}
+            raise MvlmHipError(f"mvlm_ctx_create(device={device}) failed: {reasons.get(rc, rc)}")
+        self.device = int(device)
+
+    def check(self, rc: int, exc=MvlmHipError):
+        if rc != 0:
+            msg = self.lib.mvlm_last_error(self.handle)
+            raise exc(msg.decode() if msg else f"mvlm call failed ({rc})")
+
+    def set_stream(self, stream_ptr: int):
+        self.check(self.lib.mvlm_set_stream(self.handle, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.lib.mvlm_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.mvlm_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts: dict[int, Context] = {}
+
+
+def get_context(device: int = 0) -> Context:
+    """Process-wide context per device (pipelines on one GPU share scratch and weights cache)."""
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx

@@ -1,0 +1,171 @@
+// Context, mesh upload and the single-convolution test hook of the C ABI
+// (include/mvlm_hip.h).
+#include "common.h"
+
+void* mvlm_ctx::get_scratch(const char* name, size_t bytes) {
+    auto& e = scratch[name];
+    if (e.second >= bytes && e.first) return e.first;
+    if (e.first) {
+        hipStreamSynchronize(stream);
+        hipFree(e.first);
+        e = {nullptr, 0};
+    }
+    void* p = nullptr;
+    const size_t want = bytes + bytes / 4 + 256;  // headroom so growing view counts do not realloc every call
+    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    e = {p, want};
+    return p;
+}
+
+extern "C" const char* mvlm_build_arch(void) { return "gfx950"; }
+
+extern "C" int mvlm_ctx_create(int device, mvlm_ctx** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
+    if (hipSetDevice(device) != hipSuccess) return 3;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 4;
+    auto* ctx = new mvlm_ctx();
+    ctx->device = device;
+    // the code objects in this library exist for gfx950 only - refuse anything else loudly
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        fprintf(stderr, "mvlm_hip: device %d is %s, this library is built for gfx950 (MI355X) only\n", device,
+                prop.gcnArchName);
+        delete ctx;
+        return 5;
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->scratch)
+        if (kv.second.first) hipFree(kv.second.first);
+    if (ctx->cnn.blob) hipFree(ctx->cnn.blob);
+    for (auto e : ctx->cnn.event_pool)
+        if (e) hipEventDestroy(e);
+    delete ctx;
+}
+
+extern "C" const char* mvlm_last_error(mvlm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return 0;
+}
+
+extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                                const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
+                                mvlm_mesh** out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, out, "mesh_upload: null output");
+    *out = nullptr;
+    MVLM_REQUIRE(ctx, verts_host && tris_host && n_verts > 0 && n_tris > 0, "mesh_upload: mesh does not contain any points");
+    MVLM_REQUIRE(ctx, !tex_host || (tex_h > 0 && tex_w > 0), "mesh_upload: bad texture size");
+    for (long i = 0; i < 3l * n_tris; ++i)
+        MVLM_REQUIRE(ctx, tris_host[i] >= 0 && tris_host[i] < n_verts, "mesh_upload: triangle index out of range");
+    MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    auto* m = new mvlm_mesh();
+    m->n_verts = n_verts;
+    m->n_tris = n_tris;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
+        if (hipMalloc(dst, bytes) != hipSuccess) return false;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = up((void**)&m->verts, verts_host, size_t(n_verts) * 12) && up((void**)&m->tris, tris_host, size_t(n_tris) * 12);
+    if (ok && uvs_host) ok = up((void**)&m->uvs, uvs_host, size_t(n_verts) * 8);
+    if (ok && tex_host && uvs_host) {
+        ok = up((void**)&m->tex, tex_host, size_t(tex_h) * tex_w * 3);
+        m->tex_h = tex_h;
+        m->tex_w = tex_w;
+    }
+    if (!ok) {
+        mvlm_mesh_free(nullptr, m);
+        return ctx->fail("mesh_upload: device allocation / copy failed");
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* m) {
+    (void)ctx;
+    if (!m) return;
+    if (m->verts) hipFree(m->verts);
+    if (m->uvs) hipFree(m->uvs);
+    if (m->tris) hipFree(m->tris);
+    if (m->tex) hipFree(m->tex);
+    delete m;
+}
+
+// ---- single convolution (test hook): packs the weights like mvlm_amd/weights.py does -------
+extern "C" int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host,
+                           int cout, int ksize, const float* bias_host, const float* pre_scale_host,
+                           const float* pre_shift_host, const float* post_scale_host, const float* post_shift_host,
+                           const float* r_dev, int upsample_in, float* y_dev) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, x_dev && w_host && y_dev, "conv2d: null pointer");
+    MVLM_REQUIRE(ctx, ksize == 1 || ksize == 3, "conv2d: kernel size must be 1 or 3");
+    MVLM_REQUIRE(ctx, (pre_scale_host == nullptr) == (pre_shift_host == nullptr), "conv2d: pre scale/shift come in pairs");
+    MVLM_REQUIRE(ctx, (post_scale_host == nullptr) == (post_shift_host == nullptr), "conv2d: post scale/shift come in pairs");
+    const int cin_pad = (cin + 7) / 8 * 8, cout_pad = (cout + 31) / 32 * 32, taps = ksize * ksize;
+    std::vector<float> blob;
+    auto push = [&](size_t n) {
+        const size_t off = blob.size();
+        blob.resize(off + (n + 3) / 4 * 4, 0.f);
+        return off;
+    };
+    const size_t w_off = push(size_t(taps) * cin_pad * cout_pad);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                blob[w_off + (size_t(t) * cin_pad + ci) * cout_pad + co] = w_host[(size_t(co) * cin + ci) * taps + t];
+    auto vec = [&](const float* src, int n, int n_pad) -> long {
+        if (!src) return -1;
+        const size_t off = push(n_pad);
+        for (int i = 0; i < n; ++i) blob[off + i] = src[i];
+        return long(off);
+    };
+    const long b_off = vec(bias_host, cout, cout_pad);
+    const long ps_off = vec(pre_scale_host, cin, cin_pad), pt_off = vec(pre_shift_host, cin, cin_pad);
+    const long qs_off = vec(post_scale_host, cout, cout_pad), qt_off = vec(post_shift_host, cout, cout_pad);
+    auto* d = static_cast<float*>(ctx->get_scratch("conv2d.blob", blob.size() * 4));
+    MVLM_REQUIRE(ctx, d, "conv2d: scratch allocation failed");
+    MVLM_CHECK_HIP(ctx, hipMemcpy(d, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs a;
+    a.in = x_dev;
+    a.in_ctot = cin;
+    a.cin = cin;
+    a.cin_pad = cin_pad;
+    a.up_in = upsample_in;
+    a.B = batch;
+    a.H = h;
+    a.W = w;
+    a.w = d + w_off;
+    a.cout = cout;
+    a.cout_pad = cout_pad;
+    a.ksize = ksize;
+    a.bias = b_off < 0 ? nullptr : d + b_off;
+    a.pre_scale = ps_off < 0 ? nullptr : d + ps_off;
+    a.pre_shift = pt_off < 0 ? nullptr : d + pt_off;
+    a.post_scale = qs_off < 0 ? nullptr : d + qs_off;
+    a.post_shift = qt_off < 0 ? nullptr : d + qt_off;
+    a.res1 = r_dev;
+    a.res1_ctot = cout;
+    a.out = y_dev;
+    a.out_ctot = cout;
+    if (mvlm_launch_conv(ctx, a, nullptr)) return 1;
+    MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}

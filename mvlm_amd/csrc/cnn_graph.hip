@@ -1,0 +1,466 @@
+// Graph executor for the landmark-heatmap network: walks the fixed two-stack hourglass
+// architecture of the reference (MVLMModel.forward, src/mvlm/prediction/paulsenpredictor.py
+// :404-432; ResidualBlock :267-273; HourGlassModule :301-361) and issues one fused
+// convolution launch per conv layer (138 live convs; conv8 is dead at inference, :204-205).
+//
+// What is fused where (nothing else touches HBM):
+//   BatchNorm+ReLU of a pre-activation block  -> consumer conv's input staging
+//   bias / post-BN+ReLU (conv1, conv5, conv9)  -> producer conv's epilogue
+//   torch.cat(out1,out2,out3) + residual       -> channel-slice writes + residual add in the
+//                                                 three convs' epilogues
+//   F.interpolate(x2, nearest) + skip add      -> 2x2 scatter in the epilogues of the last
+//                                                 block of the lower hourglass level
+//   F.interpolate before conv11                -> conv11 reads its input through >>1
+//   np.argmax per (view, landmark)             -> conv11's epilogue + a tiny reduction
+// Max-pools run as a separate memory-bound kernel (1-2 % of the time).
+//
+// All views of a batch go through each layer together (pixels of all views form the GEMM's
+// N dimension), so even the 4x4 hourglass level fills MFMA tiles.
+#include "common.h"
+
+namespace {
+
+struct Tensor {
+    float* p = nullptr;
+    int C = 0, S = 0;
+    size_t off = 0, elems = 0;
+};
+
+struct Block {
+    size_t off, size;
+    bool free;
+};
+
+struct Exec {
+    mvlm_ctx* ctx;
+    CnnState& st;
+    int B;
+    char* ws;
+    size_t ws_bytes;
+    bool dry;
+    size_t cursor = 0, high = 0;
+    std::vector<Block> blocks;
+    int rc = 0;
+
+    Exec(mvlm_ctx* c, int batch, void* w, size_t wb, bool d) : ctx(c), st(c->cnn), B(batch), ws((char*)w), ws_bytes(wb), dry(d) {}
+
+    Tensor alloc_raw(size_t bytes, int C, int S) {
+        bytes = (bytes + 255) / 256 * 256;
+        Tensor t;
+        t.C = C;
+        t.S = S;
+        t.elems = bytes / 4;
+        for (auto& b : blocks)
+            if (b.free && b.size == bytes) {
+                b.free = false;
+                t.off = b.off;
+                t.p = dry ? nullptr : reinterpret_cast<float*>(ws + b.off);
+                return t;
+            }
+        blocks.push_back({cursor, bytes, false});
+        t.off = cursor;
+        cursor += bytes;
+        if (cursor > high) high = cursor;
+        if (!dry && cursor > ws_bytes) {
+            rc = ctx->fail("cnn: workspace too small (mvlm_cnn_workspace_bytes)");
+            t.p = nullptr;
+            return t;
+        }
+        t.p = dry ? nullptr : reinterpret_cast<float*>(ws + t.off);
+        return t;
+    }
+    Tensor alloc(int C, int S) { return alloc_raw(size_t(B) * C * S * S * 4, C, S); }
+    void release(const Tensor& t) {
+        for (auto& b : blocks)
+            if (b.off == t.off && !b.free) {
+                b.free = true;
+                return;
+            }
+    }
+
+    const int32_t* d(int slot) const { return &st.desc[size_t(slot) * MVLM_CONV_DESC_INTS]; }
+    const float* blob(int off) const { return off < 0 ? nullptr : st.blob + off; }
+
+    // fill weights / BN / bias of `slot` into `a` and launch
+    int conv(int slot, const Tensor& x, ConvArgs a, int S) {
+        if (rc) return rc;
+        const int32_t* r = d(slot);
+        if (!r[0]) return rc = ctx->fail("cnn: conv slot not present in the packed weights");
+        a.in = x.p;
+        a.in_ctot = x.C;
+        a.in_coff = 0;
+        a.cin = r[1];
+        a.cout = r[2];
+        a.ksize = r[3];
+        a.cin_pad = r[4];
+        a.cout_pad = r[5];
+        a.w = blob(r[6]);
+        a.bias = blob(r[7]);
+        a.pre_scale = blob(r[8]);
+        a.pre_shift = blob(r[9]);
+        a.post_scale = blob(r[10]);
+        a.post_shift = blob(r[11]);
+        a.B = B;
+        a.H = a.W = S;
+        if (x.C != a.cin) return rc = ctx->fail("cnn: channel mismatch between graph and packed weights");
+        if (dry) return 0;
+        int variant = -1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (st.profiling) {
+            if (st.event_cursor + 2 > st.event_pool.size()) {
+                st.event_pool.resize(st.event_cursor + 2, nullptr);
+            }
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t& e = st.event_pool[st.event_cursor + k];
+                if (!e && hipEventCreate(&e) != hipSuccess) return rc = ctx->fail("cnn: hipEventCreate failed");
+            }
+            e0 = st.event_pool[st.event_cursor];
+            e1 = st.event_pool[st.event_cursor + 1];
+            st.event_cursor += 2;
+            hipEventRecord(e0, ctx->stream);
+        }
+        if (mvlm_launch_conv(ctx, a, &variant)) return rc = 1;
+        if (st.profiling) {
+            hipEventRecord(e1, ctx->stream);
+            const double flops = 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(S) * S * B;
+            st.prof.push_back({slot, variant, flops, e0, e1});
+        }
+        return 0;
+    }
+
+    // One pre-activation residual block (paulsenpredictor.py:267-273).
+    // hi == nullptr : returns y [cout@S]
+    // hi != nullptr : writes upsample2x(y) + *hi into *hi in place ([cout@2S], the hourglass
+    //                 skip tensor), returns an empty tensor
+    Tensor rb(int rb_index, const Tensor& x, Tensor* hi) {
+        const int base = 1 + 4 * rb_index;
+        const int S = x.S;
+        const int cout = d(base + 1)[2] * 2;
+        const int h = cout / 2, q = cout / 4;
+        const bool resample = d(base)[0] != 0;
+        Tensor y;
+        if (!hi) y = alloc(cout, S);
+        const Tensor* res = &x;
+        if (resample) {
+            if (hi) {
+                rc = ctx->fail("cnn: resampling block cannot scatter");
+                return y;
+            }
+            ConvArgs a;
+            a.out = y.p;
+            a.out_ctot = cout;
+            conv(base, x, a, S);
+            res = &y;
+        }
+        auto common = [&](ConvArgs& a, int coff) {
+            a.res1 = res->p;
+            a.res1_ctot = res->C;
+            a.res1_coff = coff;
+            if (hi) {
+                a.out = hi->p;
+                a.out_ctot = hi->C;
+                a.out_coff = coff;
+                a.up_out = 1;
+                a.skip = hi->p;
+                a.skip_ctot = hi->C;
+                a.skip_coff = coff;
+            } else {
+                a.out = y.p;
+                a.out_ctot = cout;
+                a.out_coff = coff;
+            }
+        };
+        Tensor t1 = alloc(h, S), t2 = alloc(q, S);
+        {
+            ConvArgs a;
+            a.out_raw = t1.p;
+            a.raw_ctot = h;
+            common(a, 0);
+            conv(base + 1, x, a, S);
+        }
+        {
+            ConvArgs a;
+            a.out_raw = t2.p;
+            a.raw_ctot = q;
+            common(a, h);
+            conv(base + 2, t1, a, S);
+        }
+        {
+            ConvArgs a;
+            common(a, h + q);
+            conv(base + 3, t2, a, S);
+        }
+        release(t1);
+        release(t2);
+        return y;
+    }
+
+    Tensor pool(const Tensor& x) {
+        Tensor o = alloc(x.C, x.S / 2);
+        if (!dry && !rc && mvlm_launch_maxpool2(ctx, x.p, B * x.C, x.S, x.S, o.p)) rc = 1;
+        return o;
+    }
+
+    // HourGlassModule.forward (paulsenpredictor.py:301-361).  rb0 = index of this
+    // hourglass's rb1 in the canonical residual-block order.  Consumes nothing; the caller
+    // releases x.
+    Tensor hourglass(int rb0, const Tensor& x) {
+        auto R = [&](int i) { return rb0 + i - 1; };
+        Tensor up1 = rb(R(1), x, nullptr);
+        Tensor lowt1 = pool(x);
+        Tensor low1 = rb(R(2), lowt1, nullptr);
+        release(lowt1);
+        Tensor up11 = rb(R(3), low1, nullptr);
+        Tensor lowt11 = pool(low1);
+        release(low1);
+        Tensor low11 = rb(R(4), lowt11, nullptr);
+        release(lowt11);
+        Tensor up12 = rb(R(5), low11, nullptr);
+        Tensor lowt12 = pool(low11);
+        release(low11);
+        Tensor low12 = rb(R(6), lowt12, nullptr);
+        release(lowt12);
+        Tensor up13 = rb(R(7), low12, nullptr);
+        Tensor lowt13 = pool(low12);
+        release(low12);
+        Tensor low13 = rb(R(8), lowt13, nullptr);
+        release(lowt13);
+        Tensor up14 = rb(R(9), low13, nullptr);
+        Tensor lowt14 = pool(low13);
+        release(low13);
+        Tensor low14 = rb(R(10), lowt14, nullptr);
+        release(lowt14);
+        Tensor low2 = rb(R(11), low14, nullptr);
+        release(low14);
+        rb(R(12), low2, &up14);  // add1 = up(low3) + up14, in place in up14
+        release(low2);
+        Tensor low21 = rb(R(13), up14, nullptr);
+        release(up14);
+        rb(R(14), low21, &up13);  // add2
+        release(low21);
+        Tensor low22 = rb(R(15), up13, nullptr);
+        release(up13);
+        rb(R(16), low22, &up12);  // add3
+        release(low22);
+        Tensor low23 = rb(R(17), up12, nullptr);
+        release(up12);
+        rb(R(18), low23, &up11);  // add4
+        release(low23);
+        Tensor low24 = rb(R(19), up11, nullptr);
+        release(up11);
+        rb(R(20), low24, &up1);  // add5
+        release(low24);
+        return up1;
+    }
+
+    // images: [B,256,256,4]; either maxima (+view0/n_total) or heat ([B,NL,256,256]) is set
+    int forward(const float* images, const int* sel4, float* maxima, int view0, int n_total, float* heat) {
+        const int NL = st.n_landmarks, C = st.in_channels;
+        const int SLOT_CONV5 = 1 + 4 * 43;
+        Tensor x0 = alloc(C, 256);
+        if (!dry && mvlm_launch_pack_input(ctx, images, B, sel4, C, x0.p)) return 1;
+        Tensor a0 = alloc(64, 256);
+        {
+            ConvArgs a;
+            a.out = a0.p;
+            a.out_ctot = 64;
+            conv(0, x0, a, 256);  // conv1 + bn1 + relu
+        }
+        release(x0);
+        Tensor a1 = rb(0, a0, nullptr);  // conv2
+        release(a0);
+        Tensor p1 = pool(a1);
+        release(a1);
+        Tensor a2 = rb(1, p1, nullptr);  // conv3
+        release(p1);
+        Tensor r3 = rb(2, a2, nullptr);  // conv4
+        release(a2);
+        Tensor h1 = hourglass(3, r3);
+        Tensor ll1 = alloc(256, 128);
+        {
+            ConvArgs a;
+            a.out = ll1.p;
+            a.out_ctot = 256;
+            conv(SLOT_CONV5, h1, a, 128);  // conv5 + bn2 + relu
+        }
+        release(h1);
+        Tensor x6 = alloc(NL, 128);
+        {
+            ConvArgs a;
+            a.out = x6.p;
+            a.out_ctot = NL;
+            conv(SLOT_CONV5 + 1, ll1, a, 128);  // conv6
+        }
+        Tensor sum = alloc(256, 128);
+        {
+            ConvArgs a;  // conv7; sum_temp = (r3 + ll1) + x  (:422)
+            a.res1 = r3.p;
+            a.res1_ctot = 256;
+            a.res2 = ll1.p;
+            a.res2_ctot = 256;
+            a.out = sum.p;
+            a.out_ctot = 256;
+            conv(SLOT_CONV5 + 2, x6, a, 128);
+        }
+        release(x6);
+        release(r3);
+        release(ll1);
+        Tensor h2 = hourglass(23, sum);
+        release(sum);
+        Tensor x9 = alloc(256, 128);
+        {
+            ConvArgs a;
+            a.out = x9.p;
+            a.out_ctot = 256;
+            conv(SLOT_CONV5 + 3, h2, a, 128);  // conv9 + bn3 + relu
+        }
+        release(h2);
+        Tensor x10 = alloc(NL, 128);
+        {
+            ConvArgs a;
+            a.out = x10.p;
+            a.out_ctot = NL;
+            conv(SLOT_CONV5 + 4, x9, a, 128);  // conv10
+        }
+        release(x9);
+        {
+            ConvArgs a;  // conv11 over the nearest-upsampled conv10 output (:428-429)
+            a.up_in = 1;
+            Tensor xin = x10;
+            xin.S = 256;
+            if (heat) {
+                a.out = heat;
+                a.out_ctot = NL;
+                conv(SLOT_CONV5 + 5, xin, a, 256);
+            } else {
+                const int parts = mvlm_conv_amax_parts(256, 256);
+                Tensor av = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
+                Tensor ai = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
+                a.amax_val = av.p;
+                a.amax_idx = reinterpret_cast<int*>(ai.p);
+                a.amax_parts = parts;
+                conv(SLOT_CONV5 + 5, xin, a, 256);
+                if (!dry && !rc &&
+                    mvlm_launch_amax_final(ctx, av.p, reinterpret_cast<int*>(ai.p), B, view0, n_total, NL, parts, 256,
+                                           maxima))
+                    rc = 1;
+                release(av);
+                release(ai);
+            }
+        }
+        release(x10);
+        return rc;
+    }
+};
+
+int run_cnn(mvlm_ctx* ctx, const float* images, int n_views, const int32_t* chan_sel, float* maxima, float* heat,
+            void* ws, size_t ws_bytes, int batch) {
+    CnnState& st = ctx->cnn;
+    MVLM_REQUIRE(ctx, st.loaded, "cnn: mvlm_cnn_load has not been called");
+    MVLM_REQUIRE(ctx, images && n_views > 0 && batch > 0 && ws, "cnn: bad arguments");
+    MVLM_REQUIRE(ctx, maxima || heat, "cnn: no output requested");
+    int sel4[4] = {0, 0, 0, 0};
+    for (int k = 0; k < st.in_channels; ++k) {
+        MVLM_REQUIRE(ctx, chan_sel[k] >= 0 && chan_sel[k] < 4, "cnn: channel selector out of range");
+        sel4[k] = chan_sel[k];
+    }
+    st.prof.clear();
+    st.event_cursor = 0;
+    const size_t img_elems = size_t(MVLM_IMAGE_SIZE) * MVLM_IMAGE_SIZE;
+    for (int v0 = 0; v0 < n_views; v0 += batch) {
+        const int nb = (n_views - v0) < batch ? (n_views - v0) : batch;
+        Exec ex(ctx, nb, ws, ws_bytes, false);
+        float* h = heat ? heat + size_t(v0) * st.n_landmarks * img_elems : nullptr;
+        if (ex.forward(images + size_t(v0) * img_elems * 4, sel4, maxima, v0, n_views, h)) return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_floats, const int32_t* desc_host,
+                             int n_slots, int n_landmarks, int in_channels) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, blob_host && desc_host && n_floats > 0, "cnn_load: null weights");
+    MVLM_REQUIRE(ctx, n_slots == 1 + 4 * 43 + 6, "cnn_load: descriptor table must have 179 conv slots");
+    MVLM_REQUIRE(ctx, n_landmarks > 0 && in_channels >= 1 && in_channels <= 4, "cnn_load: bad landmark / channel count");
+    CnnState& st = ctx->cnn;
+    MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (st.blob) {
+        MVLM_CHECK_HIP(ctx, hipFree(st.blob));
+        st.blob = nullptr;
+    }
+    st.loaded = false;
+    st.desc.assign(desc_host, desc_host + size_t(n_slots) * MVLM_CONV_DESC_INTS);
+    // validate every offset before anything is launched with it
+    for (int s = 0; s < n_slots; ++s) {
+        const int32_t* r = &st.desc[size_t(s) * MVLM_CONV_DESC_INTS];
+        if (!r[0]) continue;
+        MVLM_REQUIRE(ctx, r[1] > 0 && r[2] > 0 && (r[3] == 1 || r[3] == 3), "cnn_load: bad conv shape");
+        MVLM_REQUIRE(ctx, r[4] % 8 == 0 && r[4] >= r[1] && r[5] % 32 == 0 && r[5] >= r[2], "cnn_load: bad padding");
+        const size_t wsz = size_t(r[3]) * r[3] * r[4] * r[5];
+        MVLM_REQUIRE(ctx, r[6] >= 0 && size_t(r[6]) + wsz <= n_floats, "cnn_load: weight offset out of range");
+        const int offs[5] = {r[7], r[8], r[9], r[10], r[11]};
+        const int lens[5] = {r[5], r[4], r[4], r[5], r[5]};
+        for (int k = 0; k < 5; ++k)
+            MVLM_REQUIRE(ctx, offs[k] < 0 || size_t(offs[k]) + lens[k] <= n_floats, "cnn_load: vector offset out of range");
+    }
+    MVLM_REQUIRE(ctx, st.desc[1] == in_channels, "cnn_load: conv1 input channels != in_channels");
+    MVLM_REQUIRE(ctx, st.desc[size_t(n_slots - 1) * MVLM_CONV_DESC_INTS + 2] == n_landmarks,
+                 "cnn_load: conv11 output channels != n_landmarks");
+    MVLM_CHECK_HIP(ctx, hipMalloc(&st.blob, n_floats * sizeof(float)));
+    MVLM_CHECK_HIP(ctx, hipMemcpy(st.blob, blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    st.n_landmarks = n_landmarks;
+    st.in_channels = in_channels;
+    st.loaded = true;
+    return 0;
+}
+
+extern "C" size_t mvlm_cnn_workspace_bytes(mvlm_ctx* ctx, int batch) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->cnn.loaded || batch <= 0) return 0;
+    Exec ex(ctx, batch, nullptr, 0, true);
+    const int sel4[4] = {0, 0, 0, 0};
+    ex.forward(nullptr, sel4, reinterpret_cast<float*>(8), 0, batch, nullptr);
+    return ex.high + 256;
+}
+
+extern "C" int mvlm_cnn_maxima(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
+                               float* maxima_dev, void* workspace_dev, size_t workspace_bytes, int batch) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, maxima_dev && chan_sel_host, "cnn_maxima: null output / selector");
+    return run_cnn(ctx, images_dev, n_views, chan_sel_host, maxima_dev, nullptr, workspace_dev, workspace_bytes, batch);
+}
+
+extern "C" int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
+                                 float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, heat_dev && chan_sel_host, "cnn_heatmaps: null output / selector");
+    return run_cnn(ctx, images_dev, n_views, chan_sel_host, nullptr, heat_dev, workspace_dev, workspace_bytes, batch);
+}
+
+extern "C" int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->cnn.profiling = enabled != 0;
+    return 0;
+}
+
+extern "C" int mvlm_cnn_get_profile(mvlm_ctx* ctx, int32_t* slot, int32_t* variant, double* flops, float* ms, int cap) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    CnnState& st = ctx->cnn;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+    int n = 0;
+    for (const auto& r : st.prof) {
+        if (n >= cap) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;
+        slot[n] = r.slot;
+        variant[n] = r.variant;
+        flops[n] = r.flops;
+        ms[n] = t;
+        ++n;
+    }
+    return n;
+}
+
+extern "C" const char* mvlm_conv_variant_name(int variant) { return mvlm_conv_variant_name_impl(variant); }

@@ -1,0 +1,119 @@
+// Internal declarations shared by the HIP translation units of libmvlm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mvlm_hip.h"
+
+#define MVLM_CHECK_HIP(ctx, expr)                                                            \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            (ctx)->fail(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+
+#define MVLM_REQUIRE(ctx, cond, msg)                                                         \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            (ctx)->fail(std::string(msg) + " [" #cond "]");                                  \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// One convolution launch.  All tensors are planar NCHW f32; a tensor argument is a base
+// pointer + total channel count + first channel, so a launch can read or write a channel
+// slice of a wider tensor (the residual block's concat, paulsenpredictor.py:273).
+struct ConvArgs {
+    // input
+    const float* in = nullptr;
+    int in_ctot = 0, in_coff = 0;
+    int cin = 0, cin_pad = 0;
+    int up_in = 0;  // 1: input tensor is [B][C][H/2][W/2], read through nearest 2x upsampling
+    const float* pre_scale = nullptr;  // [cin_pad] BN+ReLU applied to the input; null = raw
+    const float* pre_shift = nullptr;
+    // geometry (output == conv-input spatial size)
+    int B = 0, H = 0, W = 0;
+    // weights [taps][cin_pad][cout_pad]
+    const float* w = nullptr;
+    int cout = 0, cout_pad = 0, ksize = 3;
+    const float* bias = nullptr;        // [cout_pad] or null
+    const float* post_scale = nullptr;  // [cout_pad] relu(v*s+t) or null
+    const float* post_shift = nullptr;
+    // residual(s): y = v + (res1 [+ res2])
+    const float* res1 = nullptr;
+    int res1_ctot = 0, res1_coff = 0;
+    const float* res2 = nullptr;
+    int res2_ctot = 0, res2_coff = 0;
+    // outputs
+    float* out_raw = nullptr;  // v (before residual)
+    int raw_ctot = 0, raw_coff = 0;
+    float* out = nullptr;  // v + residual
+    int out_ctot = 0, out_coff = 0;
+    int up_out = 0;  // 1: out is [B][out_ctot][2H][2W]; each value is written to its 2x2 block, + skip there
+    const float* skip = nullptr;
+    int skip_ctot = 0, skip_coff = 0;
+    // fused per-(image, channel) argmax partials (conv11): [B][cout][n_part]
+    float* amax_val = nullptr;
+    int* amax_idx = nullptr;
+    int amax_parts = 0;
+};
+
+struct ConvProfileRec {
+    int slot, variant;
+    double flops;
+    hipEvent_t e0, e1;
+};
+
+struct CnnState {
+    bool loaded = false;
+    int n_landmarks = 0, in_channels = 0;
+    float* blob = nullptr;  // device copy of the packed weights
+    std::vector<int32_t> desc;  // host copy of the descriptor table
+    bool profiling = false;
+    std::vector<ConvProfileRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_cursor = 0;
+};
+
+struct mvlm_mesh {
+    float* verts = nullptr;   // [V,3]
+    float* uvs = nullptr;     // [V,2] or null
+    int32_t* tris = nullptr;  // [T,3]
+    uint8_t* tex = nullptr;   // [H,W,3] or null
+    int n_verts = 0, n_tris = 0, tex_h = 0, tex_w = 0;
+};
+
+struct mvlm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    CnnState cnn;
+    // grow-only internal scratch (raster bins, transformed vertices, small staging)
+    std::map<std::string, std::pair<void*, size_t>> scratch;
+    int fail(const std::string& m) {
+        err = m;
+        return 1;
+    }
+    void* get_scratch(const char* name, size_t bytes);
+};
+
+// conv_mfma.hip
+int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
+int mvlm_conv_amax_parts(int H, int W);  // partials per (image, channel) the argmax epilogue writes
+const char* mvlm_conv_variant_name_impl(int v);
+
+// small kernels (misc.hip)
+int mvlm_launch_pack_input(mvlm_ctx* ctx, const float* images, int n, const int* sel4, int c, float* out);
+int mvlm_launch_maxpool2(mvlm_ctx* ctx, const float* in, int planes, int H, int W, float* out);
+int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int n_img, int view0, int n_views_total,
+                           int nl, int parts, int size, float* maxima);

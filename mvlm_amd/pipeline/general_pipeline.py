@@ -1,0 +1,238 @@
+"""``Pipeline.predict_one_file`` - the hot path's orchestrator.
+
+Same class surface as the reference's ``Pipeline``
+(src/mvlm/pipeline/general_pipeline.py:39-146): constructor kwargs, the three
+duck-typed slots ``renderer_3d`` / ``predictor_2d`` / ``estimator_3d``,
+``get_lm_count`` and ``predict_one_file(file_name, landmark_indices=None,
+view_indices=None, clip_rays_to_mesh=True) -> ndarray[NL,3] | None``.
+
+When all three slots are this package's HIP objects the call runs *fused*: the
+rendered views, the maxima and the rays never leave HBM; only the per-landmark
+survivor counts (for the host-side RANSAC draw) and the final [NL,3] result cross
+PCIe.  Any other object in a slot (a user predictor, the reference's own classes)
+is driven through the reference's numpy slot protocol instead.
+"""
+from __future__ import annotations
+
+import abc
+import time
+from pathlib import Path
+
+import numpy as np
+
+from .. import parallel
+from ..prediction.paulsenpredictor import HipPaulsenModel
+from ..utils.estimator3d import HipEstimator3D
+from ..utils.render3d import HipRenderer3D
+
+__all__ = ["Pipeline"]
+
+
+class TimeMixin:
+    def __init__(self):
+        self.start_time = time.time()
+        self.end_time = None
+
+    def tic(self):
+        self.start_time = time.time()
+
+    def toc(self):
+        self.end_time = time.time()
+        return self.end_time - self.start_time
+
+    def toc_p(self):
+        return self.p_time(self.toc())
+
+    def p_time(self, t):
+        return f"{t:08.6f} s"
+
+
+class Pipeline(abc.ABC, TimeMixin):
+    def __init__(self, render_image_stack: bool = False, offscreen: bool = True, n_views: int = 8,
+                 render_image_folder: Path | None = None, visualize_rays: bool = False,
+                 screenshot_folder: Path | None = None, device: int = 0, shard_views: bool = False,
+                 verbose: bool = True):
+        TimeMixin.__init__(self)
+        self.render_image_stack = render_image_stack
+        self.render_image_folder = render_image_folder
+        self.n_views = n_views
+        self.visualize_rays = visualize_rays
+        self.screenshot_folder = screenshot_folder
+        self.device = device
+        self.shard_views = shard_views
+        self.verbose = verbose
+        self.timings: dict[str, float] = {}
+        self.last_error: float | None = None
+
+        self.renderer_3d = HipRenderer3D(image_size=(256, 256), offscreen=offscreen, n_views=n_views, device=device,
+                                         verbose=verbose)
+        self.estimator_3d = HipEstimator3D(device=device, verbose=verbose)
+        self.predictor_2d = None  # will be assigned externally
+
+    def get_lm_count(self) -> int:
+        if self.predictor_2d is None:
+            raise ValueError("Predictor2D is not initialized.")
+        return self.predictor_2d.get_lm_count()
+
+    def _say(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def _fusable(self) -> bool:
+        return (isinstance(self.renderer_3d, HipRenderer3D) and isinstance(self.estimator_3d, HipEstimator3D)
+                and isinstance(self.predictor_2d, HipPaulsenModel))
+
+    def predict_one_file(self, file_name: Path, landmark_indices: list[int] | None = None,
+                         view_indices: list[int] | None = None, clip_rays_to_mesh: bool = True):
+        if self.predictor_2d is None:
+            raise ValueError("Predictor2D is not initialized.")
+        file_name = Path(file_name)
+        full_s = time.time()
+        if not file_name.exists():
+            print(f"File {file_name} does not exist")
+            return None
+        if self.visualize_rays:
+            print("[Pipeline] Ray visualization is not part of the MI355X hot path; skipping")
+        if self._fusable():
+            landmarks = self._predict_fused(file_name)
+        else:
+            landmarks = self._predict_slots(file_name)
+        self._say("Landmarks 3D Total: ", self.p_time(time.time() - full_s))
+        return landmarks
+
+    # ---- fused device-resident path ----------------------------------------------------
+    def predict_mesh_device(self, mesh, transform_stack):
+        """Render + network + fusion + snap for an already loaded mesh and pose table.
+        Returns (landmarks [NL,3] float64 numpy, mean RANSAC error).  With
+        ``shard_views`` under torch.distributed each rank handles a slice of the views."""
+        import torch
+
+        r3, p2, e3 = self.renderer_3d, self.predictor_2d, self.estimator_3d
+        n_total = int(transform_stack.shape[0])
+        sharded = self.shard_views and parallel.is_distributed()
+        rank, world = parallel.rank_world() if sharded else (0, 1)
+        lo, hi = parallel.shard_range(n_total, rank, world)
+
+        t0 = time.time()
+        images = r3.render_device(mesh, transform_stack[lo:hi])
+        if self.verbose:
+            torch.cuda.synchronize()
+        self.timings["render"] = time.time() - t0
+        self._say("Render [Total]: ", self.p_time(self.timings["render"]))
+        if self.render_image_stack:
+            self.visualize_image_stack(images.cpu().numpy(), mesh.path or Path("mesh.obj"), first_index=lo)
+
+        t0 = time.time()
+        maxima = p2.predict_device(images)
+        del images
+        if sharded:
+            maxima = parallel.all_gather_views(maxima, n_total)
+        if self.verbose:
+            torch.cuda.synchronize()
+        self.timings["prediction"] = time.time() - t0
+        self._say("Prediction [Total]: ", self.p_time(self.timings["prediction"]))
+
+        t0 = time.time()
+        starts, ends = e3.lines_device(maxima, transform_stack, 256)
+        self.timings["lines"] = time.time() - t0
+        self._say("Landmarks [0] - From Heatmaps: ", self.p_time(self.timings["lines"]))
+
+        t0 = time.time()
+        draw_fn = None
+        if sharded:
+            # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference),
+            # everybody uses the same table
+            table = {}
+
+            def draw_fn(lm, k, _t=table):
+                return _t[lm]
+
+            counts_probe = self._survivor_counts(maxima)
+            if rank == 0:
+                for lm, k in enumerate(counts_probe):
+                    if k >= 3:
+                        table[lm] = np.random.choice(range(int(k)), 8, replace=True)
+            table.update(parallel.broadcast_array(table if rank == 0 else None))
+        out, err, _ = e3.consensus_device(maxima, starts, ends, draw_fn=draw_fn)
+        error = e3.mean_error(err.cpu().numpy())
+        self.timings["consensus"] = time.time() - t0
+        self._say("Landmarks [1] - From View Lines: ", self.p_time(self.timings["consensus"]))
+
+        t0 = time.time()
+        landmarks = e3.project_device(mesh, out).cpu().numpy()
+        self.timings["project"] = time.time() - t0
+        self._say("Landmarks [2] - Project to Surface: ", self.p_time(self.timings["project"]))
+        self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
+        self.last_error = error
+        return landmarks, error
+
+    def _survivor_counts(self, maxima):
+        """Per-landmark count of lines that pass the filter (needed before the host draws)."""
+        import ctypes as C
+        import torch
+
+        e3 = self.estimator_3d
+        nl, n = int(maxima.shape[0]), int(maxima.shape[1])
+        mask = torch.empty((nl, n), dtype=torch.uint8, device=maxima.device)
+        count = torch.empty((nl,), dtype=torch.int32, device=maxima.device)
+        mode = {"quantile": 0, "absolute": 1}.get(e3.mode)
+        if mode is None:
+            raise ValueError(f"Unknown mode for line matching in Estimator: {e3.mode}")
+        e3.ctx.check(e3.ctx.lib.mvlm_consensus_mask(
+            e3.ctx.handle, C.c_void_p(maxima.data_ptr()), n, nl, mode, float(e3.threshold_quantile),
+            float(e3.threshold_absolute), C.c_void_p(mask.data_ptr()), C.c_void_p(count.data_ptr())), ValueError)
+        return count.cpu().numpy()
+
+    def _predict_fused(self, file_name: Path):
+        from ..utils.mesh_io import load_obj
+
+        self.tic()
+        file_name = self.renderer_3d._check_file(file_name)
+        mesh = load_obj(file_name)
+        sharded = self.shard_views and parallel.is_distributed()
+        if sharded:
+            rank, _ = parallel.rank_world()
+            poses = self.renderer_3d.generate_3d_transformations() if rank == 0 else None
+            poses = parallel.broadcast_array(poses)
+        else:
+            poses = self.renderer_3d.generate_3d_transformations()
+        self.timings["load"] = self.toc()
+        landmarks, _ = self.predict_mesh_device(mesh, poses)
+        return landmarks
+
+    # ---- the reference's numpy slot protocol (general_pipeline.py:83-108) ----------------
+    def _predict_slots(self, file_name: Path):
+        self.tic()
+        image_stack, transform_stack, pd = self.renderer_3d.multiview_render(file_name)
+        self._say("Render [Total]: ", self.toc_p())
+        if self.render_image_stack:
+            self.visualize_image_stack(image_stack, file_name)
+        self.tic()
+        landmark_stack, valid = self.predictor_2d.predict_landmarks_from_images(image_stack)
+        self._say("Prediction [Total]: ", self.toc_p())
+        landmark_stack = landmark_stack[:, valid, :]
+        transform_stack = transform_stack[valid]
+        image_stack = image_stack[valid]
+        self.tic()
+        lines_s, lines_e = self.estimator_3d.estimate_landmark_lines(image_stack, landmark_stack, transform_stack)
+        self._say("Landmarks [0] - From Heatmaps: ", self.toc_p())
+        self.tic()
+        landmarks, error = self.estimator_3d.estimate_landmarks_from_lines(landmark_stack, lines_s, lines_e)
+        self._say("Landmarks [1] - From View Lines: ", self.toc_p())
+        self.tic()
+        landmarks = self.estimator_3d.project_landmarks_to_surface(pd, landmarks)
+        self._say("Landmarks [2] - Project to Surface: ", self.toc_p())
+        self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
+        self.last_error = error
+        return landmarks
+
+    def visualize_image_stack(self, image_stack: np.ndarray, file_name: Path, first_index: int = 0):
+        """PNG dump of the rendered views (general_pipeline.py:133-146)."""
+        from PIL import Image
+
+        save_folder = self.render_image_folder or Path(file_name).parent
+        if not Path(save_folder).exists():
+            raise ValueError(f"Folder for --visualize-method flag [{save_folder}] does not exist.")
+        for i in range(image_stack.shape[0]):
+            single_image = np.uint8(image_stack[i, :, :, 0:3] * 255)
+            Image.fromarray(single_image).save(Path(save_folder) / f"{Path(file_name).stem}_{first_index + i:02d}.png")

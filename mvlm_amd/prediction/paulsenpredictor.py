@@ -1,0 +1,196 @@
+"""Landmark-heatmap predictor slot running on the MI355X.
+
+Drop-in for the reference's ``PaulsenModel`` / ``BU3DFEPredictor`` /
+``DTU3DPredictor`` (src/mvlm/prediction/paulsenpredictor.py:42-243): same
+constructor arguments and ``predict_landmarks_from_images`` /
+``get_lm_count`` contract.  The stacked-hourglass forward (:404-432), the
+batching loop (:189-212) and the heatmap maxima (:112-165) run as HIP kernels
+behind ``mvlm_cnn_maxima`` (mvlm_amd/csrc/cnn_graph.hip, conv_mfma.hip); the
+[N,NL,256,256] heatmaps are never materialised for the default "simple"
+selection method.
+"""
+from __future__ import annotations
+
+import abc
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from .. import _lib, arch, weights as W
+from .predictor2d import Predictor2D
+
+__all__ = ["HipPaulsenModel", "BU3DFEPredictor", "DTU3DPredictor", "checkpoint_basename"]
+
+# file names of the reference's published state dicts (paulsenpredictor.py:15-26); the
+# loader looks for them on disk instead of downloading
+_CHECKPOINTS = {
+    "MVLMModel_DTU3D-RGB": "MVLMModel_DTU3D_RGB_07092019_only_state_dict-c0255a70.pth",
+    "MVLMModel_DTU3D-depth": "MVLMModel_DTU3D_Depth_19092019_only_state_dict-95b89b63.pth",
+    "MVLMModel_DTU3D-geometry": "MVLMModel_DTU3D_geometry_only_state_dict-41851074.pth",
+    "MVLMModel_DTU3D-geometry+depth": "MVLMModel_DTU3D_geometry+depth_20102019_15epoch_only_state_dict-73b20e31.pth",
+    "MVLMModel_DTU3D-RGB+depth": "MVLMModel_DTU3D_RGB+depth_20092019_only_state_dict-e3c12463a9.pth",
+    "MVLMModel_BU_3DFE-RGB": "MVLMModel_BU_3DFE_RGB_24092019_6epoch_only_state_dict-eb652074.pth",
+    "MVLMModel_BU_3DFE-depth": "MVLMModel_BU_3DFE_depth_10102019_4epoch_only_state_dict-e2318093.pth",
+    "MVLMModel_BU_3DFE-geometry": "MVLMModel_BU_3DFE_geometry_02102019_4epoch-only_state_dict-f85518fa.pth",
+    "MVLMModel_BU_3DFE-RGB+depth": "MVLMModel_BU_3DFE_RGB+depth_05102019_5epoch_only_state_dict-297955f6.pth",
+    "MVLMModel_BU_3DFE-geometry+depth": "MVLMModel_BU_3DFE_geometry+depth_17102019_13epoch_only_state_dict-aa34a6d68.pth",
+}
+_URL_ROOT = "https://shapeml.compute.dtu.dk/Deep-MVLM/models/"
+
+
+def checkpoint_basename(model_type: str, image_mode: str) -> str:
+    return _CHECKPOINTS[f"{model_type}-{image_mode}"]
+
+
+class HipPaulsenModel(Predictor2D):
+    """weights: None -> look for the reference checkpoint file in ``model_dir`` /
+    ``$MVLM_MODEL_DIR`` / this package's ``models`` folder, then try the reference's
+    URL; a path -> that checkpoint; a dict -> a state dict; ``"synthetic"`` or
+    ``"synthetic:<seed>"`` -> seeded random weights (benchmarks, tests)."""
+
+    def __init__(self, model_type: str, image_mode: str, n_gpus=1, batch_size=2, selection_method="simple",
+                 weights=None, device: int = 0, device_batch: int | None = None, model_dir=None, verbose: bool = True):
+        super().__init__()
+        if image_mode not in arch.IMAGE_CHANNELS:
+            raise ValueError("Image channels should be: geometry, RGB, depth, RGB+depth or geometry+depth")
+        if selection_method not in ("simple", "moment"):
+            raise ValueError(f"unknown selection_method {selection_method!r}")
+        self.batch_size = batch_size
+        self.selection_method = selection_method
+        self.model_type = model_type
+        self.image_mode = image_mode
+        self.n_gpus = n_gpus
+        self.verbose = verbose
+        self.in_channels = arch.IMAGE_CHANNELS[image_mode]
+        self.chan_sel = np.asarray(arch.CHANNEL_SELECT[image_mode], dtype=np.int32)
+        # views pushed through the network together; the reference's batch_size=2 is a CPU
+        # memory knob and does not change any per-view result
+        self.device_batch = device_batch
+        self.ctx = _lib.Context(device)  # own context: it holds this model's weights
+        self._workspace = None
+        state_dict = self._resolve_weights(weights, model_dir)
+        blob, desc = W.pack_for_device(state_dict, self.get_lm_count(), self.in_channels)
+        self.ctx.check(self.ctx.lib.mvlm_cnn_load(
+            self.ctx.handle, _lib.as_ptr(blob, C.c_float), blob.size, _lib.as_ptr(desc, C.c_int32), desc.shape[0],
+            self.get_lm_count(), self.in_channels))
+
+    @abc.abstractmethod
+    def get_lm_count(self) -> int:
+        pass
+
+    # ---- weights ----------------------------------------------------------------------
+    def _resolve_weights(self, weights, model_dir):
+        nl, c = self.get_lm_count(), self.in_channels
+        if isinstance(weights, dict):
+            return {k: np.asarray(v) for k, v in weights.items()}
+        if isinstance(weights, str) and weights.startswith("synthetic"):
+            seed = int(weights.split(":", 1)[1]) if ":" in weights else 0
+            return W.synthetic_state_dict(nl, c, seed=seed)
+        if weights is not None:
+            return W.load_state_dict_file(weights)
+        name = checkpoint_basename(self.model_type, self.image_mode)
+        candidates = [Path(d) / name for d in (model_dir, os.environ.get("MVLM_MODEL_DIR"),
+                                                Path(__file__).parent / "models") if d]
+        for p in candidates:
+            if p.is_file():
+                return W.load_state_dict_file(p)
+        # same fallback as the reference (:94-101): fetch into the package's models folder
+        from torch.hub import load_state_dict_from_url
+
+        if self.verbose:
+            print("Loading checkpoint")
+        ckpt = load_state_dict_from_url(_URL_ROOT + name, model_dir=str(Path(__file__).parent / "models"),
+                                        map_location="cpu")
+        sd = ckpt["state_dict"] if name.find("only_state_dict") == -1 else ckpt
+        return {k: v.numpy() for k, v in sd.items()}
+
+    # ---- inference --------------------------------------------------------------------
+    def _batch_for(self, n_views: int) -> int:
+        return max(1, min(n_views, self.device_batch or 32))
+
+    def _get_workspace(self, batch: int):
+        import torch
+
+        need = int(self.ctx.lib.mvlm_cnn_workspace_bytes(self.ctx.handle, batch))
+        if need == 0:
+            raise _lib.MvlmHipError("mvlm_cnn_workspace_bytes returned 0 (weights not loaded?)")
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", self.ctx.device))
+        return self._workspace
+
+    def predict_device(self, image_stack_dev):
+        """torch f32 [N,256,256,4] on this GPU -> maxima torch f32 [NL,N,3] on the GPU."""
+        import torch
+
+        dev = torch.device("cuda", self.ctx.device)
+        if image_stack_dev.dtype != torch.float32 or tuple(image_stack_dev.shape[1:]) != (256, 256, 4):
+            raise RuntimeError(f"Unexpected image stack shape: {tuple(image_stack_dev.shape)} {image_stack_dev.dtype}")
+        x = image_stack_dev.contiguous()
+        n = int(x.shape[0])
+        nl = self.get_lm_count()
+        batch = self._batch_for(n)
+        ws = self._get_workspace(batch)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        maxima = torch.empty((nl, n, 3), dtype=torch.float32, device=dev)
+        if self.selection_method == "simple":
+            self.ctx.check(self.ctx.lib.mvlm_cnn_maxima(
+                self.ctx.handle, C.c_void_p(x.data_ptr()), n, _lib.as_ptr(self.chan_sel, C.c_int32),
+                C.c_void_p(maxima.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
+        else:  # "moment" needs the heatmap neighbourhood of each peak (:129-156)
+            for s in range(0, n, batch):
+                nb = min(batch, n - s)
+                heat = torch.empty((nb, nl, 256, 256), dtype=torch.float32, device=dev)
+                part = torch.empty((nl, nb, 3), dtype=torch.float32, device=dev)
+                self.ctx.check(self.ctx.lib.mvlm_cnn_heatmaps(
+                    self.ctx.handle, C.c_void_p(x[s:s + nb].data_ptr()), nb, _lib.as_ptr(self.chan_sel, C.c_int32),
+                    C.c_void_p(heat.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
+                self.ctx.check(self.ctx.lib.mvlm_heatmap_maxima(self.ctx.handle, C.c_void_p(heat.data_ptr()), nb, nl, 256,
+                                                                1, C.c_void_p(part.data_ptr())))
+                maxima[:, s:s + nb] = part
+        return maxima
+
+    def heatmaps_device(self, image_stack_dev):
+        """Final-stage heatmaps torch f32 [N,NL,256,256] (tests / diagnostics)."""
+        import torch
+
+        dev = torch.device("cuda", self.ctx.device)
+        x = image_stack_dev.contiguous()
+        n, nl = int(x.shape[0]), self.get_lm_count()
+        batch = self._batch_for(n)
+        ws = self._get_workspace(batch)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        heat = torch.empty((n, nl, 256, 256), dtype=torch.float32, device=dev)
+        self.ctx.check(self.ctx.lib.mvlm_cnn_heatmaps(
+            self.ctx.handle, C.c_void_p(x.data_ptr()), n, _lib.as_ptr(self.chan_sel, C.c_int32),
+            C.c_void_p(heat.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
+        return heat
+
+    def predict_landmarks_from_images(self, image_stack: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        import torch
+
+        n_views = image_stack.shape[0]
+        valid = np.ones((n_views), dtype=bool)
+        x = torch.from_numpy(np.ascontiguousarray(image_stack, dtype=np.float32)).to(torch.device("cuda", self.ctx.device))
+        lms = self.predict_device(x).cpu().numpy()
+        return lms, valid
+
+
+class BU3DFEPredictor(HipPaulsenModel):
+    def __init__(self, batch_size=2, selection_method="simple", n_gpus=1, image_mode="RGB+depth", **kw):
+        super().__init__(model_type="MVLMModel_BU_3DFE", image_mode=image_mode, n_gpus=n_gpus, batch_size=batch_size,
+                         selection_method=selection_method, **kw)
+
+    def get_lm_count(self) -> int:
+        return 84
+
+
+class DTU3DPredictor(HipPaulsenModel):
+    def __init__(self, batch_size=2, selection_method="simple", n_gpus=1, image_mode="RGB+depth", **kw):
+        super().__init__(model_type="MVLMModel_DTU3D", image_mode=image_mode, n_gpus=n_gpus, batch_size=batch_size,
+                         selection_method=selection_method, **kw)
+
+    def get_lm_count(self) -> int:
+        return 73

@@ -1,0 +1,124 @@
+"""3-D estimator slot: maxima -> rays -> per-landmark consensus -> surface snap.
+
+Drop-in for the reference's ``Estimator3D`` (src/mvlm/utils/estimator3d.py): same
+constructor, attributes (``mode``, ``threshold_quantile``, ``threshold_absolute``
+are plain attributes other code sets, dlib_pipeline.py:11-12) and methods, with
+the three Python loops replaced by HIP kernels (mvlm_amd/csrc/fusion.hip,
+surface.hip).  The one-shot RANSAC index draw stays on the host and uses the
+global numpy RNG exactly like the reference (:105), so seeding numpy reproduces
+the reference's landmarks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .mesh_io import Mesh
+from .render3d import upload_mesh, view_rotations
+
+__all__ = ["HipEstimator3D"]
+
+_MODES = {"quantile": 0, "absolute": 1}
+
+
+class HipEstimator3D:
+    def __init__(self, mode: str = "quantile", threshold_quantile: float = 0.5, threshold_absolute: float = 0.5,
+                 device: int = 0, verbose: bool = True):
+        self.mode = mode
+        self.threshold_quantile = threshold_quantile
+        self.threshold_absolute = threshold_absolute
+        self.verbose = verbose
+        self.ctx = _lib.get_context(device)
+
+    # ---- helpers ----------------------------------------------------------------------
+    def _torch(self):
+        import torch
+
+        dev = torch.device("cuda", self.ctx.device)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        return torch, dev
+
+    def lines_device(self, landmarks_dev, transform_stack, image_size: int = 256):
+        """maxima f32[NL,N,3] on device + host poses -> (starts, ends) f64[NL,N,3] on device."""
+        torch, dev = self._torch()
+        nl, n = int(landmarks_dev.shape[0]), int(landmarks_dev.shape[1])
+        rot = torch.from_numpy(view_rotations(transform_stack)).to(dev)
+        starts = torch.empty((nl, n, 3), dtype=torch.float64, device=dev)
+        ends = torch.empty_like(starts)
+        self.ctx.check(self.ctx.lib.mvlm_estimate_lines(
+            self.ctx.handle, C.c_void_p(landmarks_dev.data_ptr()), C.c_void_p(rot.data_ptr()), n, nl, int(image_size),
+            C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr())))
+        return starts, ends
+
+    def consensus_device(self, landmarks_dev, starts, ends, draw_fn=None):
+        """Filter + one-shot RANSAC + LSQ on device.  Returns (landmarks f64[NL,3] tensor,
+        per-landmark error f64[NL] tensor, counts int32[NL] numpy)."""
+        torch, dev = self._torch()
+        if self.mode not in _MODES:
+            raise ValueError(f"Unknown mode for line matching in Estimator: {self.mode}")
+        nl, n = int(landmarks_dev.shape[0]), int(landmarks_dev.shape[1])
+        mask = torch.empty((nl, n), dtype=torch.uint8, device=dev)
+        count = torch.empty((nl,), dtype=torch.int32, device=dev)
+        self.ctx.check(self.ctx.lib.mvlm_consensus_mask(
+            self.ctx.handle, C.c_void_p(landmarks_dev.data_ptr()), n, nl, _MODES[self.mode],
+            float(self.threshold_quantile), float(self.threshold_absolute), C.c_void_p(mask.data_ptr()),
+            C.c_void_p(count.data_ptr())), ValueError)
+        counts = count.cpu().numpy()
+        # the reference draws once per landmark with >= 3 surviving lines, in landmark
+        # order, from the global numpy RNG (estimator3d.py:105, :174-179)
+        draws = np.zeros((nl, 8), dtype=np.int32)
+        for lm in range(nl):
+            k = int(counts[lm])
+            if k < 3:
+                if self.verbose:
+                    print("Not enough points for good estimate of landmark lm_no", lm, k)
+                continue
+            draws[lm] = draw_fn(lm, k) if draw_fn is not None else np.random.choice(range(k), 8, replace=True)
+        draws_dev = torch.from_numpy(draws).to(dev)
+        out = torch.empty((nl, 3), dtype=torch.float64, device=dev)
+        err = torch.empty((nl,), dtype=torch.float64, device=dev)
+        self.ctx.check(self.ctx.lib.mvlm_consensus_solve(
+            self.ctx.handle, C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()), C.c_void_p(mask.data_ptr()),
+            C.c_void_p(count.data_ptr()), C.c_void_p(draws_dev.data_ptr()), n, nl, C.c_void_p(out.data_ptr()),
+            C.c_void_p(err.data_ptr())))
+        return out, err, counts
+
+    def project_device(self, mesh: Mesh, landmarks_dev):
+        torch, dev = self._torch()
+        out = torch.empty_like(landmarks_dev)
+        handle = upload_mesh(self.ctx, mesh)
+        self.ctx.check(self.ctx.lib.mvlm_project_to_surface(self.ctx.handle, handle, C.c_void_p(landmarks_dev.data_ptr()),
+                                                            int(landmarks_dev.shape[0]), C.c_void_p(out.data_ptr())))
+        return out
+
+    @staticmethod
+    def mean_error(err_per_landmark: np.ndarray) -> float:
+        """sum_error / n_landmarks with the reference's left-to-right accumulation (:180-183)."""
+        s = 0
+        for e in err_per_landmark:
+            s = s + float(e)
+        return s / len(err_per_landmark)
+
+    # ---- the reference's numpy-in / numpy-out slot methods ----------------------------
+    def estimate_landmark_lines(self, image_stack: np.ndarray, landmarks_stack: np.ndarray, transform_stack: np.ndarray):
+        torch, dev = self._torch()
+        lms = torch.from_numpy(np.ascontiguousarray(landmarks_stack, dtype=np.float32)).to(dev)
+        s, e = self.lines_device(lms, np.asarray(transform_stack), int(image_stack.shape[1]))
+        return s.cpu().numpy(), e.cpu().numpy()
+
+    def estimate_landmarks_from_lines(self, landmark_stack, lines_s, lines_e):
+        torch, dev = self._torch()
+        lms = torch.from_numpy(np.ascontiguousarray(landmark_stack, dtype=np.float32)).to(dev)
+        s = torch.from_numpy(np.ascontiguousarray(lines_s, dtype=np.float64)).to(dev)
+        e = torch.from_numpy(np.ascontiguousarray(lines_e, dtype=np.float64)).to(dev)
+        out, err, _ = self.consensus_device(lms, s, e)
+        return out.cpu().numpy(), self.mean_error(err.cpu().numpy())
+
+    def project_landmarks_to_surface(self, pd, landmarks):
+        if not isinstance(pd, Mesh):
+            raise TypeError("project_landmarks_to_surface expects the Mesh handle returned by multiview_render")
+        torch, dev = self._torch()
+        pts = torch.from_numpy(np.ascontiguousarray(landmarks, dtype=np.float64)).to(dev)
+        return self.project_device(pd, pts).cpu().numpy()

@@ -1,0 +1,132 @@
+"""Mesh ingest on the host: Wavefront OBJ + same-stem JPEG texture.
+
+Mirrors what ``obj_to_actor`` obtains from vtkOBJReader / vtkJPEGReader
+(reference src/mvlm/utils/utils3d.py:10-85): geometry as float32 points, one
+texture coordinate per point (points are duplicated where a vertex is used with
+several ``vt`` indices), polygons as triangle fans, the ``.mtl`` ignored, the
+texture looked up as ``<stem>.jpg`` next to the file and silently dropped if it
+cannot be read (:26-36).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Union
+
+import numpy as np
+
+
+@dataclass
+class Mesh:
+    """Host copy of a triangle mesh plus lazily created device handles.
+
+    This object is the opaque ``pd`` handle that ``multiview_render`` returns and
+    ``project_landmarks_to_surface`` receives (general_pipeline.py:83, :107).
+    """
+
+    verts: np.ndarray                 # [V,3] float32
+    tris: np.ndarray                  # [T,3] int32
+    uvs: np.ndarray | None = None     # [V,2] float32
+    texture: np.ndarray | None = None  # [H,W,3] uint8, row 0 = top of the image
+    path: Path | None = None
+    _device: dict = field(default_factory=dict, repr=False)
+
+    @property
+    def n_verts(self) -> int:
+        return int(self.verts.shape[0])
+
+    @property
+    def n_tris(self) -> int:
+        return int(self.tris.shape[0])
+
+
+def _parse_obj(text: str):
+    pos: list[tuple[float, float, float]] = []
+    tex: list[tuple[float, float]] = []
+    corners: dict[tuple[int, int], int] = {}
+    out_v: list[int] = []
+    out_t: list[int] = []
+    tris: list[tuple[int, int, int]] = []
+    for line in text.splitlines():
+        if not line or line[0] == "#":
+            continue
+        parts = line.split()
+        if not parts:
+            continue
+        tag = parts[0]
+        if tag == "v" and len(parts) >= 4:
+            pos.append((float(parts[1]), float(parts[2]), float(parts[3])))
+        elif tag == "vt" and len(parts) >= 3:
+            tex.append((float(parts[1]), float(parts[2])))
+        elif tag == "f" and len(parts) >= 4:
+            ids = []
+            for tok in parts[1:]:
+                f = tok.split("/")
+                vi = int(f[0])
+                vi = vi - 1 if vi > 0 else len(pos) + vi
+                ti = -1
+                if len(f) > 1 and f[1]:
+                    ti = int(f[1])
+                    ti = ti - 1 if ti > 0 else len(tex) + ti
+                key = (vi, ti)
+                idx = corners.get(key)
+                if idx is None:
+                    idx = corners[key] = len(out_v)
+                    out_v.append(vi)
+                    out_t.append(ti)
+                ids.append(idx)
+            for k in range(1, len(ids) - 1):  # polygon -> fan
+                tris.append((ids[0], ids[k], ids[k + 1]))
+    return pos, tex, out_v, out_t, tris
+
+
+def load_obj(path: Union[Path, str], load_texture: bool = True) -> Mesh:
+    path = Path(path)
+    if not path.is_file():
+        raise ValueError(f"File {path} does not exist.")  # utils3d.py:13-14
+    pos, tex, out_v, out_t, tris = _parse_obj(path.read_text(errors="replace"))
+    if len(pos) == 0:
+        raise ValueError(f"File {path} does not contain any points.")  # utils3d.py:20-21
+    pos_a = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
+    if len(tris) == 0:
+        # a point cloud: keep the points, nothing to render or to snap to
+        return Mesh(pos_a, np.zeros((0, 3), np.int32), None, None, path)
+    v_idx = np.asarray(out_v, dtype=np.int64)
+    if v_idx.min() < 0 or v_idx.max() >= len(pos):
+        raise ValueError(f"File {path} references a vertex that does not exist.")
+    verts = pos_a[v_idx]
+    uvs = None
+    t_idx = np.asarray(out_t, dtype=np.int64)
+    if len(tex) > 0 and (t_idx >= 0).any():
+        tex_a = np.asarray(tex, dtype=np.float32).reshape(-1, 2)
+        safe = np.clip(t_idx, 0, len(tex) - 1)
+        uvs = np.where((t_idx >= 0)[:, None], tex_a[safe], np.float32(0)).astype(np.float32)
+    texture = None
+    if load_texture and uvs is not None:
+        jpg = path.with_suffix(".jpg")
+        if jpg.exists():
+            try:
+                from PIL import Image
+
+                with Image.open(jpg) as im:
+                    texture = np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+            except Exception:  # noqa: BLE001 - "if we cannot load the texture, we just ignore it" (:35-36)
+                texture = None
+    return Mesh(np.ascontiguousarray(verts), np.asarray(tris, dtype=np.int32).reshape(-1, 3), uvs, texture, path)
+
+
+def write_obj(path: Union[Path, str], verts: np.ndarray, tris: np.ndarray, uvs: np.ndarray | None = None,
+              texture: np.ndarray | None = None, jpeg_quality: int = 95) -> None:
+    """Small writer used by the synthetic-mesh generator and the tests."""
+    path = Path(path)
+    lines = [f"v {x:.6f} {y:.6f} {z:.6f}" for x, y, z in np.asarray(verts, dtype=np.float64)]
+    if uvs is not None:
+        lines += [f"vt {u:.6f} {v:.6f}" for u, v in np.asarray(uvs, dtype=np.float64)]
+        lines += [f"f {a + 1}/{a + 1} {b + 1}/{b + 1} {c + 1}/{c + 1}" for a, b, c in np.asarray(tris)]
+    else:
+        lines += [f"f {a + 1} {b + 1} {c + 1}" for a, b, c in np.asarray(tris)]
+    path.write_text("\n".join(lines) + "\n")
+    if texture is not None:
+        from PIL import Image
+
+        Image.fromarray(np.asarray(texture, dtype=np.uint8)).save(path.with_suffix(".jpg"), quality=jpeg_quality)

@@ -1,0 +1,165 @@
+"""Multi-view renderer slot: all camera poses of a mesh rasterised on the MI355X.
+
+Drop-in for the reference's ``ObjVTKRenderer3D`` (src/mvlm/utils/render3d.py):
+same constructor arguments, same pose generation (global numpy RNG, same draw
+order), same ``multiview_render(path) -> (image_stack, transform_stack, mesh)``
+contract, with the per-pose VTK offscreen loop (:139-170) replaced by one
+batched HIP launch set (mvlm_amd/csrc/raster.hip) through ``mvlm_render``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from pathlib import Path
+
+import numpy as np
+
+from .. import _lib
+from .mesh_io import Mesh, load_obj
+
+__all__ = ["HipRenderer3D", "view_rotations", "upload_mesh"]
+
+
+def view_rotations(transform_stack: np.ndarray) -> np.ndarray:
+    """[N,>=3] (rx, ry, rz) degrees -> [N,9] float64 row-major M = Ry @ Rx @ Rz.
+
+    The order is VTK's RotateY / RotateX / RotateZ pre-multiplication
+    (render3d.py:140-144), which the estimator inverts (estimator3d.py:57).
+    """
+    t = np.asarray(transform_stack)
+    out = np.empty((t.shape[0], 9), dtype=np.float64)
+    for i in range(t.shape[0]):
+        rx, ry, rz = (np.deg2rad(v) for v in t[i, :3])
+        mx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+        my = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        mz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
+        out[i] = ((my @ mx) @ mz).ravel()
+    return out
+
+
+def upload_mesh(ctx: "_lib.Context", mesh: Mesh) -> C.c_void_p:
+    """Copy a host mesh to the context's device once; cached on the Mesh object."""
+    key = id(ctx)
+    ent = mesh._device.get(key)
+    if ent is not None:
+        return ent[0]
+    if mesh.n_tris == 0:
+        raise ValueError("mesh has no triangles to render")
+    verts = np.ascontiguousarray(mesh.verts, dtype=np.float32)
+    tris = np.ascontiguousarray(mesh.tris, dtype=np.int32)
+    uvs = None if mesh.uvs is None else np.ascontiguousarray(mesh.uvs, dtype=np.float32)
+    tex = None if mesh.texture is None else np.ascontiguousarray(mesh.texture, dtype=np.uint8)
+    handle = C.c_void_p()
+    ctx.check(ctx.lib.mvlm_mesh_upload(
+        ctx.handle, _lib.as_ptr(verts, C.c_float), None if uvs is None else _lib.as_ptr(uvs, C.c_float), mesh.n_verts,
+        _lib.as_ptr(tris, C.c_int32), mesh.n_tris, None if tex is None else _lib.as_ptr(tex, C.c_uint8),
+        0 if tex is None else tex.shape[0], 0 if tex is None else tex.shape[1], C.byref(handle)), ValueError)
+
+    class _Owner:  # frees the device copy with the Mesh
+        def __init__(self, ctx, h):
+            self.ctx, self.h = ctx, h
+
+        def __del__(self):
+            try:
+                self.ctx.lib.mvlm_mesh_free(self.ctx.handle, self.h)
+            except Exception:  # noqa: BLE001
+                pass
+
+    mesh._device[key] = (handle, _Owner(ctx, handle))
+    return handle
+
+
+class HipRenderer3D:
+    def __init__(self, n_views: int = 8, image_size: tuple = (256, 256), offscreen: bool = True,
+                 min_x_angle: int = -40, max_x_angle: int = 40, min_y_angle: int = -80, max_y_angle: int = 80,
+                 min_z_angle: int = -20, max_z_angle: int = 20, min_scale: float = 1.4, max_scale: float = 1.9,
+                 min_tx: int = -20, max_tx: int = 20, min_ty: int = -20, max_ty: int = 20, device: int = 0,
+                 verbose: bool = True):
+        if tuple(image_size) != (256, 256):
+            raise ValueError("the HIP renderer is built for 256x256 views (general_pipeline.py:57)")
+        self.n_views = n_views
+        self.image_size = tuple(image_size)
+        self.offscreen = offscreen  # accepted for signature compatibility; there is no window
+        self.min_x_angle, self.max_x_angle = min_x_angle, max_x_angle
+        self.min_y_angle, self.max_y_angle = min_y_angle, max_y_angle
+        self.min_z_angle, self.max_z_angle = min_z_angle, max_z_angle
+        self.min_scale, self.max_scale = min_scale, max_scale
+        self.min_tx, self.max_tx = min_tx, max_tx
+        self.min_ty, self.max_ty = min_ty, max_ty
+        self.slack = 5
+        self.side_length = max([150 - (-150), 150 - (-150)]) * 1.0 / 2  # render3d.py:50
+        self.verbose = verbose
+        self.ctx = _lib.get_context(device)
+
+    # ---- pose table (render3d.py:79-112) ----------------------------------------------
+    def random_transform(self, size=1):
+        rx = np.random.randint(self.min_x_angle, self.max_x_angle, size=size)
+        ry = np.random.randint(self.min_y_angle, self.max_y_angle, size=size)
+        rz = np.random.randint(self.min_z_angle, self.max_z_angle, size=size)
+        # drawn but unused, kept so the global RNG advances exactly as in the reference
+        scale = np.random.uniform(self.min_scale, self.max_scale, size=size)
+        tx = np.random.randint(self.min_tx, self.max_tx, size=size)
+        ty = np.random.randint(self.min_ty, self.max_ty, size=size)
+        return np.stack((rx, ry, rz, scale, tx, ty), axis=1)
+
+    def generate_3d_transformations(self):
+        if self.n_views == 8:
+            table = [[rx, ry, 0, 0, 0, 0] for rx in (30, -30) for ry in (15, -15, 45, -45)]
+            return np.array(table, dtype=np.float32)
+        return self.random_transform(size=self.n_views)
+
+    # ---- rendering --------------------------------------------------------------------
+    def render_device(self, mesh: Mesh, transform_stack: np.ndarray):
+        """Poses -> torch.float32 [N,256,256,4] on the device (RGB + depth, /255, flipped)."""
+        import torch
+
+        n = int(transform_stack.shape[0])
+        dev = torch.device("cuda", self.ctx.device)
+        out = torch.empty((n, 256, 256, 4), dtype=torch.float32, device=dev)
+        rot = np.ascontiguousarray(view_rotations(transform_stack))
+        handle = upload_mesh(self.ctx, mesh)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.check(self.ctx.lib.mvlm_render(self.ctx.handle, handle, _lib.as_ptr(rot, C.c_double), n,
+                                                C.c_void_p(out.data_ptr())))
+        return out
+
+    def render_3d_multi_rgb_geometry_depth(self, transform_stack, file_name):
+        """Signature of render3d.py:114; returns the *unscaled* 0..255 stack like the reference."""
+        tt = time.time()
+        mesh = file_name if isinstance(file_name, Mesh) else load_obj(file_name)
+        if self.verbose:
+            print("Render [1] - Setup time: ", f"{time.time() - tt:08.6f} s")
+        tt = time.time()
+        stack = self.render_device(mesh, np.asarray(transform_stack))
+        image_stack = (stack * 255.0).round().cpu().numpy()
+        if self.verbose:
+            print("Render [2] - Render", f"{time.time() - tt:08.6f} s")
+        return image_stack, mesh
+
+    def _check_file(self, file_name: Path):
+        file_name = Path(file_name)
+        if not file_name.exists():
+            raise FileNotFoundError(f"File {file_name} does not exist")
+        if not file_name.is_file():
+            raise FileNotFoundError(f"File {file_name} is not a file")
+        if not file_name.suffix == ".obj":
+            raise ValueError(f"File {file_name} is not an .obj file. Only .obj files are supported.")
+        return file_name
+
+    def multiview_render(self, file_name: Path):
+        """render3d.py:179-193 - numpy results, as the slot contract requires."""
+        t = time.time()
+        file_name = self._check_file(file_name)
+        if self.verbose:
+            print("Render [0] - Prepare", f"{time.time() - t:08.6f} s")
+        transformation_stack = self.generate_3d_transformations()
+        mesh = load_obj(file_name)
+        image_stack = self.render_device(mesh, transformation_stack).cpu().numpy()
+        return image_stack, transformation_stack, mesh
+
+    def multiview_render_device(self, file_or_mesh, transformation_stack=None):
+        """Same, but the image stack stays in HBM (used by the fused pipeline path)."""
+        mesh = file_or_mesh if isinstance(file_or_mesh, Mesh) else load_obj(self._check_file(file_or_mesh))
+        if transformation_stack is None:
+            transformation_stack = self.generate_3d_transformations()
+        return self.render_device(mesh, transformation_stack), transformation_stack, mesh

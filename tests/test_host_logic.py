@@ -1,0 +1,175 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side
+logic (OBJ ingest, configs, weight packing, view sharding) behaves like the reference."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def test_library_exports_every_declared_symbol():
+    from mvlm_amd import _lib
+
+    assert _lib.LIB_PATH.exists(), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    header = (REPO / "include" / "mvlm_hip.h").read_text()
+    declared = set(re.findall(r"\b(mvlm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mvlm_build_arch() == b"gfx950"
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mvlm_amd import _lib
+
+    with pytest.raises(_lib.MvlmHipError):
+        _lib.Context(0)
+
+
+def test_product_never_imports_oracle():
+    for p in (REPO / "mvlm_amd").rglob("*.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", p.read_text(), re.M), p
+
+
+def test_obj_ingest(tmp_path):
+    from mvlm_amd.utils.mesh_io import load_obj
+
+    (tmp_path / "a.obj").write_text(
+        "# comment\nmtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 0.5\n"
+        "vn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -4/5 -3/2 -2/3\n")
+    m = load_obj(tmp_path / "a.obj")
+    # quad -> 2 triangles (fan) + 1 triangle; vertex 1 appears with vt 1 and vt 5 -> duplicated point
+    assert m.n_tris == 3 and m.n_verts == 5
+    np.testing.assert_array_equal(m.tris[0], [0, 1, 2])
+    np.testing.assert_array_equal(m.tris[1], [0, 2, 3])
+    np.testing.assert_array_equal(m.verts[m.tris[2]], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+    np.testing.assert_array_equal(m.uvs[m.tris[2][0]], [0.5, 0.5])
+    assert m.texture is None
+    (tmp_path / "empty.obj").write_text("# nothing\n")
+    with pytest.raises(ValueError, match="does not contain any points"):
+        load_obj(tmp_path / "empty.obj")
+    with pytest.raises(ValueError, match="does not exist"):
+        load_obj(tmp_path / "nope.obj")
+    (tmp_path / "a.jpg").write_bytes(b"not a jpeg")  # unreadable texture is ignored (utils3d.py:35-36)
+    assert load_obj(tmp_path / "a.obj").texture is None
+
+
+def test_synthetic_mesh_round_trips_through_obj(tmp_path):
+    from mvlm_amd.utils.mesh_io import load_obj
+    from mvlm_amd.utils.synthetic import face_like_mesh, write_face_like_obj
+
+    p = write_face_like_obj(tmp_path / "f.obj", grid=20, tex_size=32)
+    m, ref = load_obj(p), face_like_mesh(20, 32)
+    assert m.n_tris == ref.n_tris == 2 * 19 * 19
+    np.testing.assert_allclose(m.verts[m.tris], ref.verts[ref.tris], atol=1e-5)
+    assert m.texture.shape == (32, 32, 3)
+    assert face_like_mesh(224, 8).n_tris == 99458  # the ~100k-triangle benchmark mesh
+
+
+@pytest.mark.parametrize("dataset,mode,nl,c", [("DTU3D", "RGB", 73, 3), ("BU_3DFE", "RGB+depth", 84, 4),
+                                               ("DTU3D", "geometry+depth", 73, 2), ("BU_3DFE", "depth", 84, 1)])
+def test_config_parser(tmp_path, dataset, mode, nl, c):
+    from mvlm_amd import config
+
+    d = config.default_config(dataset, mode, n_views=64)
+    d["trainer"] = {"epochs": 100}  # training keys are ignored
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(d))
+    cfg = config.load_config(p)
+    assert (cfg.n_landmarks, cfg.in_channels, cfg.n_views) == (nl, c, 64)
+    assert cfg.filter_view_lines == "quantile" and cfg.heatmap_max_quantile == 0.5
+    d["process_3d"]["filter_view_lines"] = "bogus"
+    with pytest.raises(ValueError, match="Unknown mode"):
+        config.load_config(d)
+
+
+def test_config_parser_reads_reference_files_when_present():
+    from mvlm_amd import config
+
+    ref = Path("/root/reference/configs")
+    if not ref.exists():
+        pytest.skip("reference checkout not present")
+    for f in sorted(ref.glob("*.json")):
+        cfg = config.load_config(f)
+        assert cfg.n_landmarks in (73, 84) and cfg.in_channels in (1, 2, 3, 4)
+
+
+def test_packed_weights_reproduce_conv(tmp_path):
+    """The [tap][cin_pad][cout_pad] layout + folded BN equal torch's conv/BN."""
+    from mvlm_amd import arch, weights
+
+    sd = weights.synthetic_state_dict(73, 3, seed=2)
+    blob, desc = weights.pack_for_device(sd, 73, 3)
+    assert desc.shape == (arch.N_CONV_SLOTS, weights.DESC_INTS)
+    slots = arch.conv_slots(73, 3)
+    assert sum(s.present for s in slots) == 138
+    s = next(s for s in slots if s.name == "conv4.conv1")
+    row = desc[s.index]
+    cin_pad, cout_pad = int(row[4]), int(row[5])
+    w = blob[row[6]: row[6] + 9 * cin_pad * cout_pad].reshape(9, cin_pad, cout_pad)
+    x = torch.randn(1, s.cin, 8, 8)
+    scale, shift = blob[row[8]: row[8] + s.cin], blob[row[9]: row[9] + s.cin]
+    act = torch.relu(x * torch.from_numpy(scale)[None, :, None, None] + torch.from_numpy(shift)[None, :, None, None])
+    wt = torch.from_numpy(w[:, : s.cin, : s.cout].reshape(3, 3, s.cin, s.cout).transpose(3, 2, 0, 1).copy())
+    mine = torch.nn.functional.conv2d(act, wt, None, 1, 1)
+    ref_act = torch.relu(torch.nn.functional.batch_norm(
+        x, torch.from_numpy(sd["conv4.bn1.running_mean"]), torch.from_numpy(sd["conv4.bn1.running_var"]),
+        torch.from_numpy(sd["conv4.bn1.weight"]), torch.from_numpy(sd["conv4.bn1.bias"]), False, 0.1, 1e-5))
+    ref = torch.nn.functional.conv2d(ref_act, torch.from_numpy(sd["conv4.conv1.weight"]), None, 1, 1)
+    assert torch.allclose(mine, ref, atol=1e-5)
+    assert (w[:, s.cin:, :] == 0).all() and (w[:, :, s.cout:] == 0).all()
+    torch.save({"state_dict": {("module." + k): torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, tmp_path / "ck.pth")
+    back = weights.load_state_dict_file(tmp_path / "ck.pth")  # full checkpoint saved from DataParallel
+    np.testing.assert_array_equal(back["conv11.bias"], sd["conv11.bias"])
+    bad = dict(sd)
+    bad.pop("bn3.weight")
+    with pytest.raises(KeyError):
+        weights.pack_for_device(bad, 73, 3)
+
+
+def test_pose_table_and_rotations_match_oracle():
+    from mvlm_amd.utils.render3d import HipRenderer3D, view_rotations
+    from oracle import estimator as oest
+    from oracle import poses as oposes
+
+    r = HipRenderer3D.__new__(HipRenderer3D)  # pose logic needs no GPU
+    r.__dict__.update(dict(n_views=64, min_x_angle=-40, max_x_angle=40, min_y_angle=-80, max_y_angle=80,
+                           min_z_angle=-20, max_z_angle=20, min_scale=1.4, max_scale=1.9, min_tx=-20, max_tx=20,
+                           min_ty=-20, max_ty=20))
+    np.random.seed(0)
+    mine = r.generate_3d_transformations()
+    np.random.seed(0)
+    np.testing.assert_array_equal(mine, oposes.generate_3d_transformations(64))
+    r.n_views = 8
+    np.testing.assert_array_equal(r.generate_3d_transformations(), oposes.generate_3d_transformations(8))
+    rot = view_rotations(mine)
+    for i in range(64):
+        np.testing.assert_array_equal(rot[i].reshape(3, 3), oest.view_rotation(*mine[i, :3]))
+
+
+def test_shard_range_covers_views_in_order():
+    from mvlm_amd.parallel import shard_range
+
+    for n in (8, 12, 96, 97, 128):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_create_pipeline_names():
+    from mvlm_amd import pipeline
+
+    with pytest.raises(ValueError, match="Unknown pipeline"):
+        pipeline.create_pipeline("nope")
+    with pytest.raises(ValueError, match="third-party"):
+        pipeline.create_pipeline("MediaPipe")
