@@ -80,6 +80,11 @@ def load():
         raise MvlmHipError(
             f"{LIB_PATH} not found - the MI355X HIP library is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C mvlm_amd/csrc`.")
+    # torch ships its own ROCm runtime; import it first so this library binds to the same
+    # libamdhip64 instance the tensors we are handed live in (two runtimes in one process
+    # do not see each other's devices or allocations)
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -29,18 +29,31 @@
 //   (paulsenpredictor.py:273), the hourglass "upsample + skip add" (:334-359) as a 2x2
 //   scatter, and for the last layer the per-(view, landmark) argmax
 //   (paulsenpredictor.py:123) so the [N,NL,256,256] heatmaps never reach HBM.
+#include <type_traits>
+
 #include "common.h"
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
 
-constexpr int CK = 8;  // input channels per LDS stage
 constexpr unsigned INVALID_OFF = 0xFFFFFFFFu;
 
-template <int COUT_T_, int TW_, int TRI_, int NIMG_, int KS_>
+// compile-time loop: the body sees its index as a constant, so register arrays indexed by it
+// can never be demoted to scratch by an unrolling heuristic
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// COUT_T x (TW x TRI x NIMG) output tile, KS x KS taps, CK input channels per LDS stage
+template <int COUT_T_, int TW_, int TRI_, int NIMG_, int KS_, int CK_>
 struct Cfg {
-    static constexpr int COUT_T = COUT_T_, TW = TW_, TRI = TRI_, NIMG = NIMG_, KS = KS_;
+    static constexpr int COUT_T = COUT_T_, TW = TW_, TRI = TRI_, NIMG = NIMG_, KS = KS_, CK = CK_;
     static constexpr int TAPS = KS * KS;
     static constexpr int HALO = KS / 2;
     static constexpr int PW = TW + 2 * HALO;
@@ -50,21 +63,119 @@ struct Cfg {
     static constexpr int XT = CK * PLANE;
     static constexpr int XT_PAD = (XT + 3) / 4 * 4;
     static constexpr int WT = TAPS * CK * COUT_T;
+    static constexpr int STAGE = XT_PAD + WT;  // floats per LDS stage (two stages)
     static constexpr int MT = COUT_T / 32;
     static constexpr int NT = PIX_T / 4 / 32;
+    static constexpr int KSTEPS = TAPS * CK / 2;
     static constexpr int X_ITERS = (XT + 255) / 256;
     static constexpr int W_ITERS = (WT / 4 + 255) / 256;
-    static constexpr size_t LDS_BYTES = size_t(XT_PAD + WT) * 4;
+    static constexpr int BN_MAXC = 256;  // pre-BN scale/shift of up to 256 input channels live in LDS
+    static constexpr size_t LDS_BYTES = size_t(2 * STAGE + 2 * BN_MAXC) * 4;
+    // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
+    // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
+    static constexpr int ACC_REGS = (COUT_T / 32) * (TW * TRI * NIMG / 128) * 16;
+    static constexpr int MAX_WAVES_PER_EU = ACC_REGS >= 96 ? 1 : 2;
     static_assert(PIX_T % 128 == 0, "pixel tile must split into 4 waves x 32-pixel MFMA columns");
     static_assert(COUT_T % 32 == 0, "cout tile must be a multiple of the 32-row MFMA tile");
+    static_assert(CK % 2 == 0, "the f32 MFMA consumes two k values per step");
+    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's 160 KiB LDS");
 };
 
+// ---- pieces of the main loop, as force-inlined functions over register arrays -----------
+template <class C>
+__device__ __forceinline__ void issue_loads(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
+                                            const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
+                                            float (&xv)[C::X_ITERS], f32x4 (&wv)[C::W_ITERS],
+                                            float (&bn_s)[C::X_ITERS], float (&bn_t)[C::X_ITERS]) {
+    // Loads are unconditional (out-of-tile / padding elements read element 0 and are zeroed
+    // afterwards): a branch around a load makes the compiler wait for each one separately.
+#pragma unroll
+    for (int i = 0; i < C::X_ITERS; ++i) {
+        const int c = cb + (tid + i * 256) / C::PLANE;
+        const bool ok = goff[i] != INVALID_OFF && c < a.cin;
+        const size_t off = ok ? size_t(goff[i]) + size_t(cb) * HWin : size_t(0);
+        xv[i] = a.in[off];
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_ITERS; ++i) {
+        const size_t off = woff_g[i] != INVALID_OFF ? size_t(woff_g[i]) + size_t(cb) * a.cout_pad : size_t(0);
+        wv[i] = *reinterpret_cast<const f32x4*>(a.w + off);
+    }
+    // this chunk's BatchNorm scale / shift per staged element, from the LDS copy
+    if (a.pre_scale != nullptr) {
+#pragma unroll
+        for (int i = 0; i < C::X_ITERS; ++i) {
+            const int c = cb + (tid + i * 256) / C::PLANE;
+            const int cc = c < a.cin_pad ? c : 0;
+            bn_s[i] = sbn[cc];
+            bn_t[i] = sbn[C::BN_MAXC + cc];
+        }
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void write_stage(const ConvArgs& a, int cb, int tid, float* st,
+                                            const unsigned (&goff)[C::X_ITERS], const float (&xv)[C::X_ITERS],
+                                            const f32x4 (&wv)[C::W_ITERS], const float (&bn_s)[C::X_ITERS],
+                                            const float (&bn_t)[C::X_ITERS]) {
+    const bool has_pre = a.pre_scale != nullptr;
+#pragma unroll
+    for (int i = 0; i < C::X_ITERS; ++i) {
+        const int e = tid + i * 256;
+        const int c = cb + e / C::PLANE;
+        const bool ok = goff[i] != INVALID_OFF && c < a.cin;
+        float v = xv[i];
+        if (has_pre) v = fmaxf(fmaf(v, bn_s[i], bn_t[i]), 0.f);
+        v = ok ? v : 0.f;  // zero padding is inserted after the activation
+        if (e < C::XT) st[e] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_ITERS; ++i) {
+        const int f = tid + i * 256;
+        if (f < C::WT / 4) reinterpret_cast<f32x4*>(st + C::XT_PAD)[f] = wv[i];
+    }
+}
+
+// operands of k-step s+1 are fetched from LDS while the MFMAs of step s issue
+template <class C>
+__device__ __forceinline__ void compute_stage(const float* st, int woff, const int (&pixoff)[C::NT],
+                                              f32x16 (&acc)[C::MT][C::NT]) {
+    float av[2][C::MT], bv[2][C::NT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) av[0][m] = st[woff + m * 32];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) bv[0][n] = st[pixoff[n]];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const int nx = ks + 1;
+        if (nx < C::KSTEPS) {
+            const int tap = nx / (C::CK / 2), cp = nx % (C::CK / 2);
+            const int toff = (tap / C::KS) * C::PW + (tap % C::KS);
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) av[nx & 1][m] = st[woff + (tap * C::CK + 2 * cp) * C::COUT_T + m * 32];
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n) bv[nx & 1][n] = st[2 * cp * C::PLANE + pixoff[n] + toff];
+        }
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+        // the next step's LDS reads were issued above; do not let them drift behind these MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
+// Software-pipelined main loop, one workgroup (4 waves, one per SIMD) per CU-resident tile:
+//   while the MFMAs of K-chunk c run out of LDS stage c&1, the global loads of chunk c+1 are
+//   in flight into registers; after the MFMAs they get their BatchNorm+ReLU and are written to
+//   the other stage; ONE barrier per chunk.  The kernel may use the whole 512-register file
+//   (launch bounds 256,1), so nothing spills and the 128 accumulators stay in registers.
 template <class C, bool AMAX>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
-                                                        const int cout_tiles) {
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, C::MAX_WAVES_PER_EU))) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                           const int cout_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sX = smem;
-    float* sW = smem + C::XT_PAD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,8 +218,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
         const int ys = a.up_in ? (y >> 1) : y, xs = a.up_in ? (x >> 1) : x;
         goff[i] = ok ? (unsigned(b * a.in_ctot + a.in_coff + c) * HWin + unsigned(ys * Win + xs)) : INVALID_OFF;
     }
+    // weight slice: float4 index f -> (tap, c, cout4); the source offset is chunk-invariant
+    // apart from the channel base
+    unsigned woff_g[C::W_ITERS];
+#pragma unroll
+    for (int i = 0; i < C::W_ITERS; ++i) {
+        const int f = tid + i * 256;
+        const int row = f / (C::COUT_T / 4);
+        const int c4 = f - row * (C::COUT_T / 4);
+        const int tap = row / C::CK;
+        const int c = row - tap * C::CK;
+        woff_g[i] = (f < C::WT / 4) ? unsigned((tap * a.cin_pad + c) * a.cout_pad + co0 + c4 * 4) : INVALID_OFF;
+    }
 
-    // ---- per-lane pixel offsets inside sX for the NT pixel columns of this wave ------
+    // ---- per-lane operand offsets inside a stage ---------------------------------------
     int pixoff[C::NT];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
@@ -119,84 +242,43 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
         const int img = rr / C::TRI;
         pixoff[n] = (img * C::PH + yl) * C::PW + x + half * C::PLANE;
     }
-    const int woff = half * C::COUT_T + l31;
+    const int woff = C::XT_PAD + half * C::COUT_T + l31;
 
     f32x16 acc[C::MT][C::NT];
 #pragma unroll
     for (int m = 0; m < C::MT; ++m)
 #pragma unroll
-        for (int n = 0; n < C::NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        for (int n = 0; n < C::NT; ++n) acc[m][n] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    const bool has_pre = a.pre_scale != nullptr;
+    float xv[C::X_ITERS];
+    f32x4 wv[C::W_ITERS];
 
-    for (int cb = 0; cb < a.cin_pad; cb += CK) {
-        // -------- stage input tile: global -> (BN+ReLU) -> LDS ------------------------
-        float xv[C::X_ITERS];
-#pragma unroll
-        for (int i = 0; i < C::X_ITERS; ++i) {
-            const int c = cb + (tid + i * 256) / C::PLANE;
-            const bool ok = goff[i] != INVALID_OFF && c < a.cin;
-            xv[i] = ok ? a.in[size_t(goff[i]) + size_t(cb) * HWin] : 0.f;
-        }
-        // -------- stage weight slice --------------------------------------------------
-        float4 wv[C::W_ITERS];
-#pragma unroll
-        for (int i = 0; i < C::W_ITERS; ++i) {
-            const int f = tid + i * 256;
-            if (f < C::WT / 4) {
-                const int row = f / (C::COUT_T / 4);
-                const int c4 = f - row * (C::COUT_T / 4);
-                const int tap = row / CK;
-                const int c = row - tap * CK;
-                wv[i] = *reinterpret_cast<const float4*>(a.w + (size_t(tap) * a.cin_pad + cb + c) * a.cout_pad + co0 +
-                                                         c4 * 4);
-            }
-        }
-        if (has_pre) {
-#pragma unroll
-            for (int i = 0; i < C::X_ITERS; ++i) {
-                const int c = cb + (tid + i * 256) / C::PLANE;
-                const bool ok = goff[i] != INVALID_OFF && c < a.cin;
-                if (ok) {
-                    const float s = a.pre_scale[c], t = a.pre_shift[c];
-                    xv[i] = fmaxf(fmaf(xv[i], s, t), 0.f);
-                }
-            }
-        }
-        __syncthreads();  // previous chunk's MFMA reads are done
-#pragma unroll
-        for (int i = 0; i < C::X_ITERS; ++i) {
-            const int e = tid + i * 256;
-            if (e < C::XT) sX[e] = xv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < C::W_ITERS; ++i) {
-            const int f = tid + i * 256;
-            if (f < C::WT / 4) reinterpret_cast<float4*>(sW)[f] = wv[i];
+    // the consumer-side BatchNorm (scale, shift per input channel) is read from LDS
+    float* sbn = smem + 2 * C::STAGE;
+    if (a.pre_scale != nullptr) {
+        for (int i = tid; i < a.cin_pad; i += 256) {
+            sbn[i] = a.pre_scale[i];
+            sbn[C::BN_MAXC + i] = a.pre_shift[i];
         }
         __syncthreads();
-
-        // -------- taps x channel pairs of MFMAs --------------------------------------
-#pragma unroll
-        for (int tap = 0; tap < C::TAPS; ++tap) {
-            const int toff = (tap / C::KS) * C::PW + (tap % C::KS);
-#pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
-                float av[C::MT], bv[C::NT];
-#pragma unroll
-                for (int m = 0; m < C::MT; ++m) av[m] = sW[(tap * CK + 2 * cp) * C::COUT_T + m * 32 + woff];
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n) bv[n] = sX[2 * cp * C::PLANE + pixoff[n] + toff];
-#pragma unroll
-                for (int m = 0; m < C::MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < C::NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-            }
-        }
     }
+    float bn_s[C::X_ITERS], bn_t[C::X_ITERS];
+    issue_loads<C>(a, 0, tid, HWin, sbn, goff, woff_g, xv, wv, bn_s, bn_t);
+    write_stage<C>(a, 0, tid, smem, goff, xv, wv, bn_s, bn_t);
+    __syncthreads();
+
+    int cur = 0;
+    for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
+        // in flight while the previous chunk's MFMAs run
+        issue_loads<C>(a, cb, tid, HWin, sbn, goff, woff_g, xv, wv, bn_s, bn_t);
+        // keep the compiler from sinking the loads below the MFMA block towards their use
+        __builtin_amdgcn_sched_barrier(0);
+        compute_stage<C>(smem + cur * C::STAGE, woff, pixoff, acc);
+        write_stage<C>(a, cb, tid, smem + (cur ^ 1) * C::STAGE, goff, xv, wv, bn_s, bn_t);
+        __syncthreads();  // next stage complete; everybody is done reading this one
+        cur ^= 1;
+    }
+    compute_stage<C>(smem + cur * C::STAGE, woff, pixoff, acc);
 
     // ---------------------------------- epilogue ---------------------------------------
     const size_t HW = size_t(H) * W;
@@ -210,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
         pb[n] = b < a.B ? b : -1;
         ppix[n] = (y0 + rr % C::TRI) * W + x0 + p % C::TW;
     }
-#pragma unroll
-    for (int m = 0; m < C::MT; ++m) {
+    static_for<0, C::MT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -252,13 +334,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
                 }
             }
         }
-    }
+    });
 
     if constexpr (AMAX) {
         // Fused heatmap argmax (paulsenpredictor.py:123): conv11 has no residual / post-BN, so
         // the heatmap value is acc + bias.  First maximum in row-major order wins ties.
-#pragma unroll
-        for (int m = 0; m < C::MT; ++m) {
+        static_for<0, C::MT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -287,25 +369,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
                     a.amax_idx[o] = best_i;
                 }
             }
-        }
+        });
     }
 }
 
 // ---- variant table ---------------------------------------------------------------------
 // id, name, instantiation.  W >= 32 uses row-segment tiles; smaller levels fold rows /
 // images into the 32-pixel MFMA column.
-#define MVLM_CONV_VARIANTS(X)                                  \
-    X(0, "conv3x3_c128_t8x32", Cfg<128, 32, 8, 1, 3>)          \
-    X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3>)            \
-    X(2, "conv3x3_c64_t16x32", Cfg<64, 32, 16, 1, 3>)          \
-    X(3, "conv3x3_c32_t16x32", Cfg<32, 32, 16, 1, 3>)          \
-    X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1>)          \
-    X(5, "conv3x3_c128_t16x16", Cfg<128, 16, 16, 1, 3>)        \
-    X(6, "conv3x3_c64_t16x16", Cfg<64, 16, 16, 1, 3>)          \
-    X(7, "conv3x3_c128_t8x8x4", Cfg<128, 8, 8, 4, 3>)          \
-    X(8, "conv3x3_c64_t8x8x4", Cfg<64, 8, 8, 4, 3>)            \
-    X(9, "conv3x3_c128_t4x4x16", Cfg<128, 4, 4, 16, 3>)        \
-    X(10, "conv3x3_c64_t4x4x16", Cfg<64, 4, 4, 16, 3>)
+#define MVLM_CONV_VARIANTS(X)                                   \
+    X(0, "conv3x3_c128_t8x32", Cfg<128, 32, 8, 1, 3, 8>)        \
+    X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3, 8>)          \
+    X(2, "conv3x3_c64_t16x32", Cfg<64, 32, 16, 1, 3, 8>)        \
+    X(3, "conv3x3_c32_t16x32", Cfg<32, 32, 16, 1, 3, 8>)        \
+    X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 16>)       \
+    X(5, "conv3x3_c32_t8x16", Cfg<32, 16, 8, 1, 3, 16>)         \
+    X(6, "conv3x3_c32_t8x8x2", Cfg<32, 8, 8, 2, 3, 16>)         \
+    X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -314,7 +393,8 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
     const int cout_tiles = a.cout_pad / C::COUT_T;
     MVLM_REQUIRE(ctx, a.W % C::TW == 0 && a.H % C::TRI == 0, "conv: spatial size not a multiple of the tile");
     MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
-    MVLM_REQUIRE(ctx, a.cin_pad % CK == 0, "conv: cin_pad must be a multiple of 8");
+    MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
+    MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
     if (a.amax_val) {
         MVLM_REQUIRE(ctx, C::NIMG == 1, "conv: fused argmax needs one image per tile");
         MVLM_REQUIRE(ctx, a.amax_parts == tiles_x * tiles_y * 4, "conv: argmax partial count mismatch");
@@ -322,6 +402,15 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
     }
     const long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
+    static bool attr_set = false;
+    if (!attr_set) {
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS == 3)
+            MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+        attr_set = true;
+    }
     if (a.amax_val) {
         if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS == 3) {
             hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream,
@@ -338,18 +427,17 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
 }
 
 int pick_variant(const ConvArgs& a) {
-    if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
-    const bool c128 = a.cout_pad % 128 == 0;
-    const bool c64 = a.cout_pad % 64 == 0;
+    if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0 && a.cin_pad % 16 == 0) ? 4 : -1;
     if (a.W >= 32) {
-        if (c128) return 0;
+        if (a.cout_pad % 128 == 0) return 0;
         if (a.cout_pad % 96 == 0) return 1;
-        if (c64) return (a.H % 16 == 0) ? 2 : -1;
+        if (a.cout_pad % 64 == 0) return (a.H % 16 == 0) ? 2 : -1;
         return (a.H % 16 == 0) ? 3 : -1;
     }
-    if (a.W == 16) return c128 ? 5 : (c64 ? 6 : -1);
-    if (a.W == 8) return c128 ? 7 : (c64 ? 8 : -1);
-    if (a.W == 4) return c128 ? 9 : (c64 ? 10 : -1);
+    if (a.cin_pad % 16 != 0) return -1;
+    if (a.W == 16) return 5;
+    if (a.W == 8) return 6;
+    if (a.W == 4) return 7;
     return -1;
 }
 
