@@ -124,6 +124,7 @@ def main():
     # per-kernel HIP events on the launch stream, live over the timed region
     ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 1)
     prof = {}
+    per_slot = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -141,6 +142,10 @@ def main():
             p[0] += fl[i]
             p[1] += ms[i]
             p[2] += 1
+            q = per_slot.setdefault((slot[i], var[i]), [0.0, 0.0, 0])
+            q[0] += fl[i]
+            q[1] += ms[i]
+            q[2] += 1
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0)
@@ -170,6 +175,12 @@ def main():
             for k, (f, t_ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 log(f"  {ctx.lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt // args.steps:3d}  "
                     f"{t_ms / args.steps:8.3f} ms/step  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
+        if os.environ.get("MVLM_BENCH_PER_LAYER"):
+            names = [sl.name for sl in arch.conv_slots(nl, c)]
+            sizes = arch.conv_spatial_sizes()
+            for (sl, v), (f, t_ms, cnt) in sorted(per_slot.items()):
+                log(f"    slot {sl:3d} {names[sl]:22s} @{sizes[names[sl]]:3d} {ctx.lib.mvlm_conv_variant_name(v).decode():22s} "
+                    f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
         log("stage seconds (last step):", {k: round(v, 5) for k, v in pipe.timings.items()})
         cpu = None
         if args.cpu_views > 0:

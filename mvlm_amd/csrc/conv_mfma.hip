@@ -82,75 +82,81 @@ struct Cfg {
 };
 
 // ---- pieces of the main loop, as force-inlined functions over register arrays -----------
+// One "item" is one staged element per thread: items [0, X_ITERS) are input-tile floats,
+// items [X_ITERS, X_ITERS + W_ITERS) are float4s of the weight slice.
 template <class C>
-__device__ __forceinline__ void issue_loads(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
-                                            const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
-                                            float (&xv)[C::X_ITERS], f32x4 (&wv)[C::W_ITERS],
-                                            float (&bn_s)[C::X_ITERS], float (&bn_t)[C::X_ITERS]) {
-    // Loads are unconditional (out-of-tile / padding elements read element 0 and are zeroed
-    // afterwards): a branch around a load makes the compiler wait for each one separately.
-#pragma unroll
-    for (int i = 0; i < C::X_ITERS; ++i) {
-        const int c = cb + (tid + i * 256) / C::PLANE;
-        const bool ok = goff[i] != INVALID_OFF && c < a.cin;
-        const size_t off = ok ? size_t(goff[i]) + size_t(cb) * HWin : size_t(0);
-        xv[i] = a.in[off];
-    }
-#pragma unroll
-    for (int i = 0; i < C::W_ITERS; ++i) {
-        const size_t off = woff_g[i] != INVALID_OFF ? size_t(woff_g[i]) + size_t(cb) * a.cout_pad : size_t(0);
-        wv[i] = *reinterpret_cast<const f32x4*>(a.w + off);
-    }
-    // this chunk's BatchNorm scale / shift per staged element, from the LDS copy
-    if (a.pre_scale != nullptr) {
-#pragma unroll
-        for (int i = 0; i < C::X_ITERS; ++i) {
-            const int c = cb + (tid + i * 256) / C::PLANE;
+struct StageRegs {
+    float xv[C::X_ITERS];
+    f32x4 wv[C::W_ITERS];
+    float bn_s[C::X_ITERS], bn_t[C::X_ITERS];
+};
+
+// Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
+// padding elements read element 0 and are zeroed at write time): a branch around a load makes
+// the compiler wait for each one separately.
+template <class C, int T>
+__device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
+                                           const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
+                                           StageRegs<C>& r) {
+    if constexpr (T < C::X_ITERS) {
+        const int c = cb + (tid + T * 256) / C::PLANE;
+        const bool ok = goff[T] != INVALID_OFF && c < a.cin;
+        const size_t off = ok ? size_t(goff[T]) + size_t(cb) * HWin : size_t(0);
+        r.xv[T] = a.in[off];
+        if (a.pre_scale != nullptr) {  // this element's BatchNorm scale / shift from the LDS copy
             const int cc = c < a.cin_pad ? c : 0;
-            bn_s[i] = sbn[cc];
-            bn_t[i] = sbn[C::BN_MAXC + cc];
+            r.bn_s[T] = sbn[cc];
+            r.bn_t[T] = sbn[C::BN_MAXC + cc];
         }
+    } else {
+        constexpr int I = T - C::X_ITERS;
+        const size_t off = woff_g[I] != INVALID_OFF ? size_t(woff_g[I]) + size_t(cb) * a.cout_pad : size_t(0);
+        r.wv[I] = *reinterpret_cast<const f32x4*>(a.w + off);
     }
 }
 
-template <class C>
-__device__ __forceinline__ void write_stage(const ConvArgs& a, int cb, int tid, float* st,
-                                            const unsigned (&goff)[C::X_ITERS], const float (&xv)[C::X_ITERS],
-                                            const f32x4 (&wv)[C::W_ITERS], const float (&bn_s)[C::X_ITERS],
-                                            const float (&bn_t)[C::X_ITERS]) {
-    const bool has_pre = a.pre_scale != nullptr;
-#pragma unroll
-    for (int i = 0; i < C::X_ITERS; ++i) {
-        const int e = tid + i * 256;
+// BatchNorm + ReLU (pre-activation block), zero padding AFTER the activation, then the LDS write
+template <class C, int T>
+__device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, float* st,
+                                           const unsigned (&goff)[C::X_ITERS], const StageRegs<C>& r) {
+    if constexpr (T < C::X_ITERS) {
+        const int e = tid + T * 256;
         const int c = cb + e / C::PLANE;
-        const bool ok = goff[i] != INVALID_OFF && c < a.cin;
-        float v = xv[i];
-        if (has_pre) v = fmaxf(fmaf(v, bn_s[i], bn_t[i]), 0.f);
-        v = ok ? v : 0.f;  // zero padding is inserted after the activation
+        const bool ok = goff[T] != INVALID_OFF && c < a.cin;
+        float v = r.xv[T];
+        if (a.pre_scale != nullptr) v = fmaxf(fmaf(v, r.bn_s[T], r.bn_t[T]), 0.f);
+        v = ok ? v : 0.f;
         if (e < C::XT) st[e] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < C::W_ITERS; ++i) {
-        const int f = tid + i * 256;
-        if (f < C::WT / 4) reinterpret_cast<f32x4*>(st + C::XT_PAD)[f] = wv[i];
+    } else {
+        constexpr int I = T - C::X_ITERS;
+        const int f = tid + I * 256;
+        if (f < C::WT / 4) reinterpret_cast<f32x4*>(st + C::XT_PAD)[f] = r.wv[I];
     }
 }
 
-// operands of k-step s+1 are fetched from LDS while the MFMAs of step s issue
-template <class C>
-__device__ __forceinline__ void compute_stage(const float* st, int woff, const int (&pixoff)[C::NT],
-                                              f32x16 (&acc)[C::MT][C::NT]) {
+// The MFMAs of one K-chunk out of LDS stage `st`.  Operands of k-step s+1 are fetched from LDS
+// while the MFMAs of step s issue.  With STAGE_NEXT the staging of the next chunk (cb_next) is
+// spread over the k-steps so its address arithmetic, loads, BatchNorm and LDS writes run in the
+// shadow of the 64-cycle MFMAs: loads are issued during the first half of the steps, written to
+// the other stage `st_next` half a chunk (~9k cycles) later.
+template <class C, bool STAGE_NEXT>
+__device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st, float* st_next, int cb_next, int tid,
+                                              unsigned HWin, const float* sbn, int woff, const int (&pixoff)[C::NT],
+                                              const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
+                                              StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT]) {
+    constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
+    constexpr int HALF = C::KSTEPS / 2;
     float av[2][C::MT], bv[2][C::NT];
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) av[0][m] = st[woff + m * 32];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) bv[0][n] = st[pixoff[n]];
-#pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const int nx = ks + 1;
-        if (nx < C::KSTEPS) {
-            const int tap = nx / (C::CK / 2), cp = nx % (C::CK / 2);
-            const int toff = (tap / C::KS) * C::PW + (tap % C::KS);
+    static_for<0, C::KSTEPS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int nx = ks + 1;
+        if constexpr (nx < C::KSTEPS) {
+            constexpr int tap = nx / (C::CK / 2), cp = nx % (C::CK / 2);
+            constexpr int toff = (tap / C::KS) * C::PW + (tap % C::KS);
 #pragma unroll
             for (int m = 0; m < C::MT; ++m) av[nx & 1][m] = st[woff + (tap * C::CK + 2 * cp) * C::COUT_T + m * 32];
 #pragma unroll
@@ -161,11 +167,17 @@ __device__ __forceinline__ void compute_stage(const float* st, int woff, const i
 #pragma unroll
             for (int n = 0; n < C::NT; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
-        // the next step's LDS reads were issued above; do not let them drift behind these MFMAs
+        if constexpr (STAGE_NEXT) {
+            static_for<0, T_TOT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr ((t * HALF) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r);
+                if constexpr (HALF + (t * HALF) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
+            });
+        }
+        // keep each step's LDS prefetch and side work inside its own MFMA shadow
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
-
 
 // Software-pipelined main loop, one workgroup (4 waves, one per SIMD) per CU-resident tile:
 //   while the MFMAs of K-chunk c run out of LDS stage c&1, the global loads of chunk c+1 are
@@ -173,7 +185,7 @@ __device__ __forceinline__ void compute_stage(const float* st, int woff, const i
 //   the other stage; ONE barrier per chunk.  The kernel may use the whole 512-register file
 //   (launch bounds 256,1), so nothing spills and the 128 accumulators stay in registers.
 template <class C, bool AMAX>
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, C::MAX_WAVES_PER_EU))) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                            const int cout_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -250,9 +262,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, C::MA
 #pragma unroll
         for (int n = 0; n < C::NT; ++n) acc[m][n] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    float xv[C::X_ITERS];
-    f32x4 wv[C::W_ITERS];
-
     // the consumer-side BatchNorm (scale, shift per input channel) is read from LDS
     float* sbn = smem + 2 * C::STAGE;
     if (a.pre_scale != nullptr) {
@@ -262,23 +271,25 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, C::MA
         }
         __syncthreads();
     }
-    float bn_s[C::X_ITERS], bn_t[C::X_ITERS];
-    issue_loads<C>(a, 0, tid, HWin, sbn, goff, woff_g, xv, wv, bn_s, bn_t);
-    write_stage<C>(a, 0, tid, smem, goff, xv, wv, bn_s, bn_t);
+    StageRegs<C> regs;
+    constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value>(a, 0, tid, HWin, sbn, goff, woff_g, regs); });
+    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, 0, tid, smem, goff, regs); });
     __syncthreads();
 
     int cur = 0;
     for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
-        // in flight while the previous chunk's MFMAs run
-        issue_loads<C>(a, cb, tid, HWin, sbn, goff, woff_g, xv, wv, bn_s, bn_t);
-        // keep the compiler from sinking the loads below the MFMA block towards their use
-        __builtin_amdgcn_sched_barrier(0);
-        compute_stage<C>(smem + cur * C::STAGE, woff, pixoff, acc);
-        write_stage<C>(a, cb, tid, smem + (cur ^ 1) * C::STAGE, goff, xv, wv, bn_s, bn_t);
+#if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
+        compute_chunk<C, false>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+                                goff, woff_g, regs, acc);
+#else
+        compute_chunk<C, true>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+                               goff, woff_g, regs, acc);
+#endif
         __syncthreads();  // next stage complete; everybody is done reading this one
         cur ^= 1;
     }
-    compute_stage<C>(smem + cur * C::STAGE, woff, pixoff, acc);
+    compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc);
 
     // ---------------------------------- epilogue ---------------------------------------
     const size_t HW = size_t(H) * W;
@@ -377,11 +388,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, C::MA
 // id, name, instantiation.  W >= 32 uses row-segment tiles; smaller levels fold rows /
 // images into the 32-pixel MFMA column.
 #define MVLM_CONV_VARIANTS(X)                                   \
-    X(0, "conv3x3_c128_t8x32", Cfg<128, 32, 8, 1, 3, 8>)        \
-    X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3, 8>)          \
-    X(2, "conv3x3_c64_t16x32", Cfg<64, 32, 16, 1, 3, 8>)        \
-    X(3, "conv3x3_c32_t16x32", Cfg<32, 32, 16, 1, 3, 8>)        \
-    X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 16>)       \
+    X(0, "conv3x3_c128_t8x32", Cfg<128, 32, 8, 1, 3, 4>)        \
+    X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3, 4>)          \
+    X(2, "conv3x3_c64_t16x32", Cfg<64, 32, 16, 1, 3, 4>)        \
+    X(3, "conv3x3_c32_t16x32", Cfg<32, 32, 16, 1, 3, 4>)        \
+    X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 8>)        \
     X(5, "conv3x3_c32_t8x16", Cfg<32, 16, 8, 1, 3, 16>)         \
     X(6, "conv3x3_c32_t8x8x2", Cfg<32, 8, 8, 2, 3, 16>)         \
     X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)
@@ -427,7 +438,7 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
 }
 
 int pick_variant(const ConvArgs& a) {
-    if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0 && a.cin_pad % 16 == 0) ? 4 : -1;
+    if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
     if (a.W >= 32) {
         if (a.cout_pad % 128 == 0) return 0;
         if (a.cout_pad % 96 == 0) return 1;

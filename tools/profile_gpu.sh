@@ -15,7 +15,7 @@ for f in $(find $OUT/trace -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stat
 head -40 $OUT/kernel_stats.csv
 if [ "${PMC:-1}" = "1" ]; then
   echo "== pmc sq" | tee -a $OUT/log.txt
-  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err
   echo "rc=$?" >> $OUT/log.txt
   echo "== pmc fetch" | tee -a $OUT/log.txt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
