@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--views-per-gpu", type=int, default=64)
-    ap.add_argument("--device-batch", type=int, default=32)
+    ap.add_argument("--device-batch", type=int, default=128)
     ap.add_argument("--cpu-views", type=int, default=8, help="views in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dataset", default="DTU3D")
     ap.add_argument("--image-mode", default="RGB")
@@ -165,8 +165,17 @@ def main():
             achieved = f / (t_ms * 1e-3) / 1e12
             total_f = sum(p[0] for p in prof.values())
             total_ms = sum(p[1] for p in prof.values())
+            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC pass of the same
+            # command (FETCH_SIZE x2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); the
+            # counters cannot be read from inside this process, so the newest profiles/rNN_traffic.json is used
+            traffic = None
+            tfiles = sorted((REPO / "profiles").glob("r*_traffic.json"))
+            if tfiles:
+                rec = json.loads(tfiles[-1].read_text()).get(ctx.lib.mvlm_conv_variant_name(dom).decode())
+                if rec:
+                    traffic = round(rec["hbm_bytes_per_launch"])
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel": ctx.lib.mvlm_conv_variant_name(dom).decode(),
                     "kernel_avg_ms": round(t_ms / cnt, 4), "kernel_launches_per_step": cnt // args.steps,
                     "kernel_share_of_conv_time": round(t_ms / total_ms, 3),

@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
     X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 8>)        \
     X(5, "conv3x3_c32_t8x16", Cfg<32, 16, 8, 1, 3, 16>)         \
     X(6, "conv3x3_c32_t8x8x2", Cfg<32, 8, 8, 2, 3, 16>)         \
-    X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)
+    X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)         \
+    X(8, "conv3x3_c128_t4x32", Cfg<128, 32, 4, 1, 3, 4>)        \
+    X(9, "conv3x3_c64_t4x32", Cfg<64, 32, 4, 1, 3, 4>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -440,9 +442,17 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
 int pick_variant(const ConvArgs& a) {
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
     if (a.W >= 32) {
-        if (a.cout_pad % 128 == 0) return 0;
+        // two workgroups fit a CU: below ~512 workgroups the 128-pixel tiles fill the chip better
+        const long px = long(a.B) * a.H * a.W;
+        if (a.cout_pad % 128 == 0) {
+            const long blocks = px / 256 * (a.cout_pad / 128);
+            return (blocks < 512 && !a.amax_val) ? 8 : 0;
+        }
         if (a.cout_pad % 96 == 0) return 1;
-        if (a.cout_pad % 64 == 0) return (a.H % 16 == 0) ? 2 : -1;
+        if (a.cout_pad % 64 == 0) {
+            const long blocks = px / 512 * (a.cout_pad / 64);
+            return (blocks < 512 || a.H % 16 != 0) ? 9 : 2;
+        }
         return (a.H % 16 == 0) ? 3 : -1;
     }
     if (a.cin_pad % 16 != 0) return -1;

@@ -65,8 +65,9 @@ class HipPaulsenModel(Predictor2D):
         self.verbose = verbose
         self.in_channels = arch.IMAGE_CHANNELS[image_mode]
         self.chan_sel = np.asarray(arch.CHANNEL_SELECT[image_mode], dtype=np.int32)
-        # views pushed through the network together; the reference's batch_size=2 is a CPU
-        # memory knob and does not change any per-view result
+        # views pushed through the network together (default: all, up to 128; ~113 MB of HBM
+        # scratch per view); the reference's batch_size=2 is a CPU memory knob and does not
+        # change any per-view result
         self.device_batch = device_batch
         self.ctx = _lib.Context(device)  # own context: it holds this model's weights
         self._workspace = None
@@ -108,7 +109,7 @@ class HipPaulsenModel(Predictor2D):
 
     # ---- inference --------------------------------------------------------------------
     def _batch_for(self, n_views: int) -> int:
-        return max(1, min(n_views, self.device_batch or 32))
+        return max(1, min(n_views, self.device_batch or 128))
 
     def _get_workspace(self, batch: int):
         import torch

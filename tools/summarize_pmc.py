@@ -40,3 +40,25 @@ for k in names[:24]:
         print("   FETCH_SIZE KB raw %.0f -> x2 = %.1f MB   WRITE_SIZE KB %.0f = %.1f MB   (summed over %d / %d dispatches)" % (
             a.get("FETCH_SIZE", 0), 2 * a.get("FETCH_SIZE", 0) / 1024, a.get("WRITE_SIZE", 0), a.get("WRITE_SIZE", 0) / 1024,
             cnt.get((k, "FETCH_SIZE"), 0), cnt.get((k, "WRITE_SIZE"), 0)))
+
+# per-launch HBM traffic of the conv variants, for bench.py's roofline.traffic
+import json
+import re
+VARIANT = {"128, 32, 8, 1, 3, 4": "conv3x3_c128_t8x32", "96, 32, 8, 1, 3, 4": "conv3x3_c96_t8x32",
+           "64, 32, 16, 1, 3, 4": "conv3x3_c64_t16x32", "32, 32, 16, 1, 3, 4": "conv3x3_c32_t16x32",
+           "128, 32, 8, 1, 1, 8": "conv1x1_c128_t8x32", "32, 16, 8, 1, 3, 16": "conv3x3_c32_t8x16",
+           "32, 8, 8, 2, 3, 16": "conv3x3_c32_t8x8x2", "32, 4, 4, 8, 3, 16": "conv3x3_c32_t4x4x8",
+           "128, 32, 4, 1, 3, 4": "conv3x3_c128_t4x32", "64, 32, 4, 1, 3, 4": "conv3x3_c64_t4x32"}
+traffic = {}
+for k, a in agg.items():
+    m = re.search(r"Cfg<([^>]*)>, (true|false)", k)
+    if not m or m.group(1) not in VARIANT or m.group(2) != "false":
+        continue
+    nf, nw = cnt.get((k, "FETCH_SIZE"), 0), cnt.get((k, "WRITE_SIZE"), 0)
+    if not nf or not nw:
+        continue
+    fetch = 2 * a["FETCH_SIZE"] * 1024 / nf   # gfx950: FETCH_SIZE counts half the bytes of wide reads
+    write = a["WRITE_SIZE"] * 1024 / nw
+    traffic[VARIANT[m.group(1)]] = {"launches": nf, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                                    "hbm_bytes_per_launch": fetch + write}
+(out / "traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True))
