@@ -89,11 +89,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    # MVLM_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single GPU (gloo, every rank on
+    # device 0); the real run is one rank per GPU over RCCL ("nccl" backend on ROCm)
+    share_gpu = os.environ.get("MVLM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from mvlm_amd import arch, config, parallel, weights
     from mvlm_amd.utils.synthetic import face_like_mesh
@@ -150,7 +158,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -60,7 +60,13 @@ def all_gather_views(local, n_total: int):
     send = torch.zeros((n_max, nl, 3), dtype=local.dtype, device=local.device)
     send[: local.shape[1]] = local.permute(1, 0, 2)
     recv = torch.empty((world * n_max, nl, 3), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous())
+    if dist.get_backend() == "gloo" and send.is_cuda:
+        # rehearsal on one GPU (several ranks share a device, which RCCL refuses): stage through the host
+        r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r_cpu, send.cpu().contiguous())
+        recv.copy_(r_cpu)
+    else:
+        dist.all_gather_into_tensor(recv, send.contiguous())
     parts = []
     for r in range(world):
         s, e = shard_range(n_total, r, world)

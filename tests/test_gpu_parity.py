@@ -369,3 +369,51 @@ def test_full_size_render_is_deterministic_and_view_consistent():
     assert torch.equal(a, b)                       # bin order is racy, the image must not be
     c = r.render_device(m, poses[40:41])
     assert torch.equal(a[40:41], c)                # a view does not depend on its batch
+
+
+# --------------------------------------------------------------------------------------
+# view sharding end to end: two ranks (sharing the one GPU of the test box, gloo) must return
+# exactly what a single process returns
+def _shard_worker(rank, world, port, obj, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mvlm_amd import pipeline
+
+    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False, shard_views=True)
+    np.random.seed(4 if rank == 0 else 99)  # only rank 0's RNG may matter
+    out = pipe.predict_one_file(obj)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_sharded_views_equal_single_process(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    obj = write_face_like_obj(tmp_path / "face.obj", grid=40, tex_size=64, seed=2)
+    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False)
+    np.random.seed(4)
+    want = pipe.predict_one_file(obj)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, obj, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0], want)
+    np.testing.assert_array_equal(res[1], want)
