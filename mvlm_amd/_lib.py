@@ -12,7 +12,8 @@ import subprocess
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libmvlm_hip.so"
+# MVLM_HIP_LIB: load an alternative build of the same ABI (kernel ablation experiments)
+LIB_PATH = Path(os.environ["MVLM_HIP_LIB"]) if os.environ.get("MVLM_HIP_LIB") else _HERE / "lib" / "libmvlm_hip.so"
 CSRC = _HERE / "csrc"
 
 c_float_p = C.POINTER(C.c_float)

@@ -29,6 +29,8 @@
 //   (paulsenpredictor.py:273), the hourglass "upsample + skip add" (:334-359) as a 2x2
 //   scatter, and for the last layer the per-(view, landmark) argmax
 //   (paulsenpredictor.py:123) so the [N,NL,256,256] heatmaps never reach HBM.
+#include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "common.h"
@@ -74,7 +76,8 @@ struct Cfg {
     // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
     // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
     static constexpr int ACC_REGS = (COUT_T / 32) * (TW * TRI * NIMG / 128) * 16;
-    static constexpr int MAX_WAVES_PER_EU = ACC_REGS >= 96 ? 1 : 2;
+    // register budget per lane: 168 at three workgroups per CU, 256 at two
+    static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
     static_assert(PIX_T % 128 == 0, "pixel tile must split into 4 waves x 32-pixel MFMA columns");
     static_assert(COUT_T % 32 == 0, "cout tile must be a multiple of the 32-row MFMA tile");
     static_assert(CK % 2 == 0, "the f32 MFMA consumes two k values per step");
@@ -101,8 +104,8 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
     if constexpr (T < C::X_ITERS) {
         const int c = cb + (tid + T * 256) / C::PLANE;
         const bool ok = goff[T] != INVALID_OFF && c < a.cin;
-        const size_t off = ok ? size_t(goff[T]) + size_t(cb) * HWin : size_t(0);
-        r.xv[T] = a.in[off];
+        const float* const base = a.in + size_t(cb) * HWin;  // wave-uniform
+        r.xv[T] = ok ? base[goff[T]] : a.in[0];
         if (a.pre_scale != nullptr) {  // this element's BatchNorm scale / shift from the LDS copy
             const int cc = c < a.cin_pad ? c : 0;
             r.bn_s[T] = sbn[cc];
@@ -110,8 +113,8 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
         }
     } else {
         constexpr int I = T - C::X_ITERS;
-        const size_t off = woff_g[I] != INVALID_OFF ? size_t(woff_g[I]) + size_t(cb) * a.cout_pad : size_t(0);
-        r.wv[I] = *reinterpret_cast<const f32x4*>(a.w + off);
+        const float* const base = a.w + size_t(cb) * a.cout_pad;  // wave-uniform
+        r.wv[I] = *reinterpret_cast<const f32x4*>(base + (woff_g[I] != INVALID_OFF ? woff_g[I] : 0u));
     }
 }
 
@@ -162,18 +165,31 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
 #pragma unroll
             for (int n = 0; n < C::NT; ++n) bv[nx & 1][n] = st[2 * cp * C::PLANE + pixoff[n] + toff];
         }
-#pragma unroll
-        for (int m = 0; m < C::MT; ++m)
-#pragma unroll
-            for (int n = 0; n < C::NT; ++n)
+        // two MFMAs first, then this step's share of the staging work, then the rest: the side
+        // work's LDS / VMEM operations complete in the shadow of the remaining MFMAs instead of
+        // being waited for at the next step's lgkmcnt(0)
+        constexpr int LEAD = (C::MT * C::NT >= 4) ? 2 : 1;
+        static_for<0, C::MT * C::NT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int m = i / C::NT, n = i % C::NT;
+            if constexpr (i < LEAD)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (STAGE_NEXT) {
             static_for<0, T_TOT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 if constexpr ((t * HALF) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r);
                 if constexpr (HALF + (t * HALF) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
             });
+            __builtin_amdgcn_sched_barrier(0);
         }
+        static_for<0, C::MT * C::NT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int m = i / C::NT, n = i % C::NT;
+            if constexpr (i >= LEAD)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+        });
         // keep each step's LDS prefetch and side work inside its own MFMA shadow
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -185,7 +201,7 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
 //   the other stage; ONE barrier per chunk.  The kernel may use the whole 512-register file
 //   (launch bounds 256,1), so nothing spills and the 128 accumulators stay in registers.
 template <class C, bool AMAX>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
+__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
                                                            const int cout_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -291,61 +307,161 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
     }
     compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc);
 
+#if defined(MVLM_ABLATE_NO_EPILOGUE)  // timing experiment only: wrong results
+    {
+        float sacc = 0.f;
+        static_for<0, C::MT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[m][n][r];
+        });
+        if (sacc == 123.456f) a.out[0] = sacc;
+        return;
+    }
+#endif
     // ---------------------------------- epilogue ---------------------------------------
-    const size_t HW = size_t(H) * W;
-    // per pixel column of this wave: image, flat pixel index, validity
-    int pb[C::NT], ppix[C::NT];
+    // Addresses are wave-uniform channel bases (scalar registers) + one 32-bit per-lane offset per
+    // tensor and pixel column, so an element costs a load/add/store, not 64-bit vector arithmetic.
+    const unsigned HW = unsigned(H) * unsigned(W);
+    bool lane_ok[C::NT];
+    int ppix[C::NT];
+    unsigned o_raw[C::NT], o_r1[C::NT], o_r2[C::NT], o_out[C::NT], o_skip[C::NT];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int p = wave * (C::PIX_T / 4) + n * 32 + l31;
         const int rr = p / C::TW;
         const int b = b0 + rr / C::TRI;
-        pb[n] = b < a.B ? b : -1;
-        ppix[n] = (y0 + rr % C::TRI) * W + x0 + p % C::TW;
+        const int y = y0 + rr % C::TRI, x = x0 + p % C::TW;
+        lane_ok[n] = C::NIMG == 1 ? true : (b < a.B);
+        const unsigned bb = lane_ok[n] ? unsigned(b) : 0u;
+        const unsigned pix = unsigned(y * W + x);
+        const unsigned h4 = 4u * unsigned(half);
+        ppix[n] = int(pix);
+        o_raw[n] = (bb * a.raw_ctot + a.raw_coff + h4) * HW + pix;
+        o_r1[n] = (bb * a.res1_ctot + a.res1_coff + h4) * HW + pix;
+        o_r2[n] = (bb * a.res2_ctot + a.res2_coff + h4) * HW + pix;
+        if (!a.up_out) {
+            o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * HW + pix;
+            o_skip[n] = 0;
+        } else {
+            const unsigned o2 = unsigned(2 * y) * unsigned(2 * W) + unsigned(2 * x);
+            o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * (4u * HW) + o2;
+            o_skip[n] = (bb * a.skip_ctot + a.skip_coff + h4) * (4u * HW) + o2;
+        }
     }
-    static_for<0, C::MT>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
+    // Channels are walked in groups of four accumulator registers (= four consecutive channels
+    // per half-wave).  The residual values of group g+1 are loaded (unconditionally, clamped
+    // addresses) before group g is finished and stored, so a load's latency is paid once per
+    // group of 4*NT elements instead of once per element, and the feature flags cost one
+    // wave-uniform branch per group.
+    constexpr int GE = 4 * C::NT;       // elements per group
+    constexpr int NG = C::MT * 4;       // groups per wave
+    auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;  // every channel row of this tile exists
+        float resv[2][GE];
+        auto group_base = [&](int g) { return co0 + (g >> 2) * 32 + 8 * (g & 3); };  // wave-uniform first channel
+        auto load_group = [&](auto gc, float (&dst)[GE]) {
+            constexpr int g = decltype(gc)::value;
+            if (a.res1) {
+                const int cs0 = group_base(g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool co_ok = co < a.cout;
-            const int coc = co_ok ? co : 0;
-            const float bias = a.bias ? a.bias[coc] : 0.f;
-            const float ps = a.post_scale ? a.post_scale[coc] : 1.f;
-            const float pt = a.post_scale ? a.post_shift[coc] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    // clamp the row so padded channel rows still read inside the tensor
+                    const int cs = (FULL || cs0 + j + 4 < a.cout) ? cs0 + j : 0;
+                    const float* const p1 = a.res1 + size_t(cs) * HW;
 #pragma unroll
-            for (int n = 0; n < C::NT; ++n) {
-                if (co_ok && pb[n] >= 0) {
-                    const size_t b = size_t(pb[n]);
-                    const size_t pix = size_t(ppix[n]);
-                    float v = acc[m][n][r];
+                    for (int n = 0; n < C::NT; ++n) dst[j * C::NT + n] = p1[o_r1[n]];
+                }
+                if (a.res2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cs = (FULL || cs0 + j + 4 < a.cout) ? cs0 + j : 0;
+                        const float* const p2 = a.res2 + size_t(cs) * HW;
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) dst[j * C::NT + n] += p2[o_r2[n]];
+                    }
+                }
+            }
+        };
+        load_group(std::integral_constant<int, 0>{}, resv[0]);
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int m = g >> 2, rg = g & 3;
+            if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, resv[(g + 1) & 1]);
+            const int cs0 = group_base(g);
+            float vals[GE];
+            bool okc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = cs0 + j + 4 * half;
+                okc[j] = FULL || co < a.cout;
+                const int coc = okc[j] ? co : 0;
+                const float bias = a.bias ? a.bias[coc] : 0.f;
+                const float ps = a.post_scale ? a.post_scale[coc] : 1.f;
+                const float pt = a.post_scale ? a.post_shift[coc] : 0.f;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) {
+                    float v = acc[m][n][4 * rg + j];
                     if (a.bias) v += bias;
                     if (a.post_scale) v = fmaxf(fmaf(v, ps, pt), 0.f);
-                    if (a.out_raw) a.out_raw[(b * a.raw_ctot + a.raw_coff + co) * HW + pix] = v;
-                    if (a.res1) {
-                        float rv = a.res1[(b * a.res1_ctot + a.res1_coff + co) * HW + pix];
-                        if (a.res2) rv += a.res2[(b * a.res2_ctot + a.res2_coff + co) * HW + pix];
-                        v += rv;
+                    vals[j * C::NT + n] = v;
+                }
+            }
+            if (a.out_raw) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* const p = a.out_raw + size_t(cs0 + j) * HW;
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+                        if (okc[j] && lane_ok[n]) p[o_raw[n]] = vals[j * C::NT + n];
+                }
+            }
+            if (a.res1) {
+#pragma unroll
+                for (int e = 0; e < GE; ++e) vals[e] += resv[g & 1][e];
+            }
+            if (a.out) {
+                if (!a.up_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* const p = a.out + size_t(cs0 + j) * HW;
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n)
+                            if (okc[j] && lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
                     }
-                    if (a.out) {
-                        if (!a.up_out) {
-                            a.out[(b * a.out_ctot + a.out_coff + co) * HW + pix] = v;
-                        } else {
-                            const int y = ppix[n] / W, x = ppix[n] - y * W;
-                            const size_t W2 = size_t(W) * 2;
-                            const size_t o2 = size_t(2 * y) * W2 + 2 * x;
-                            const size_t obase = (b * a.out_ctot + a.out_coff + co) * HW * 4 + o2;
-                            const size_t sbase = (b * a.skip_ctot + a.skip_coff + co) * HW * 4 + o2;
-                            const float2 s0 = *reinterpret_cast<const float2*>(a.skip + sbase);
-                            const float2 s1 = *reinterpret_cast<const float2*>(a.skip + sbase + W2);
-                            *reinterpret_cast<float2*>(a.out + obase) = make_float2(v + s0.x, v + s0.y);
-                            *reinterpret_cast<float2*>(a.out + obase + W2) = make_float2(v + s1.x, v + s1.y);
+                } else {
+                    const unsigned W2 = 2u * unsigned(W);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the row's skip loads first, then its 2x2 scatter
+                        const int cs = okc[j] ? cs0 + j : 0;
+                        const float* const ps = a.skip + size_t(cs) * HW * 4;
+                        float* const p = a.out + size_t(cs0 + j) * HW * 4;
+                        float2 s0[C::NT], s1[C::NT];
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) {
+                            s0[n] = *reinterpret_cast<const float2*>(ps + o_skip[n]);
+                            s1[n] = *reinterpret_cast<const float2*>(ps + o_skip[n] + W2);
+                        }
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) {
+                            if (okc[j] && lane_ok[n]) {
+                                const float v = vals[j * C::NT + n];
+                                *reinterpret_cast<float2*>(p + o_out[n]) = make_float2(v + s0[n].x, v + s0[n].y);
+                                *reinterpret_cast<float2*>(p + o_out[n] + W2) = make_float2(v + s1[n].x, v + s1[n].y);
+                            }
                         }
                     }
                 }
             }
-        }
-    });
+        });
+    };
+    if (co0 + C::COUT_T <= a.cout)
+        epilogue(std::true_type{});
+    else
+        epilogue(std::false_type{});
 
     if constexpr (AMAX) {
         // Fused heatmap argmax (paulsenpredictor.py:123): conv11 has no residual / post-BN, so
@@ -362,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n) {
                     const float v = acc[m][n][r] + bias;
-                    const bool better = pb[n] >= 0 && (v > best_v || (v == best_v && ppix[n] < best_i));
+                    const bool better = lane_ok[n] && (v > best_v || (v == best_v && ppix[n] < best_i));
                     best_v = better ? v : best_v;
                     best_i = better ? ppix[n] : best_i;
                 }
@@ -397,7 +513,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a, con
     X(6, "conv3x3_c32_t8x8x2", Cfg<32, 8, 8, 2, 3, 16>)         \
     X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)         \
     X(8, "conv3x3_c128_t4x32", Cfg<128, 32, 4, 1, 3, 4>)        \
-    X(9, "conv3x3_c64_t4x32", Cfg<64, 32, 4, 1, 3, 4>)
+    X(9, "conv3x3_c64_t4x32", Cfg<64, 32, 4, 1, 3, 4>)          \
+    X(10, "conv3x3_c64_t8x32", Cfg<64, 32, 8, 1, 3, 4>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -440,18 +557,23 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
 }
 
 int pick_variant(const ConvArgs& a) {
+    // experiment knob: MVLM_CONV_TILE=small forces the 128-pixel tiles wherever they exist
+    static const bool force_small = [] {
+        const char* e = getenv("MVLM_CONV_TILE");
+        return e && std::string(e) == "small";
+    }();
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
     if (a.W >= 32) {
         // two workgroups fit a CU: below ~512 workgroups the 128-pixel tiles fill the chip better
         const long px = long(a.B) * a.H * a.W;
         if (a.cout_pad % 128 == 0) {
             const long blocks = px / 256 * (a.cout_pad / 128);
-            return (blocks < 512 && !a.amax_val) ? 8 : 0;
+            return ((blocks < 512 || force_small) && !a.amax_val) ? 8 : 0;
         }
         if (a.cout_pad % 96 == 0) return 1;
         if (a.cout_pad % 64 == 0) {
-            const long blocks = px / 512 * (a.cout_pad / 64);
-            return (blocks < 512 || a.H % 16 != 0) ? 9 : 2;
+            const long blocks = px / 256 * (a.cout_pad / 64);
+            return (blocks < 768 || force_small) ? 9 : 10;
         }
         return (a.H % 16 == 0) ? 3 : -1;
     }
@@ -485,8 +607,13 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     MVLM_REQUIRE(ctx, a.H == a.W, "conv: square feature maps only");
     MVLM_REQUIRE(ctx, !a.up_in || (a.H % 2 == 0), "conv: upsampled input needs even size");
     MVLM_REQUIRE(ctx, !a.up_out || a.skip, "conv: up_out needs a skip tensor");
-    const double in_elems = double(a.B) * a.in_ctot * a.H * a.W;
-    MVLM_REQUIRE(ctx, in_elems < 4.0e9, "conv: input tensor exceeds 32-bit element offsets");
+    const double px = double(a.B) * a.H * a.W, lim = 4294967295.0;
+    MVLM_REQUIRE(ctx, px * a.in_ctot < lim, "conv: input tensor exceeds 32-bit element offsets (lower the batch)");
+    MVLM_REQUIRE(ctx, !a.out_raw || px * a.raw_ctot < lim, "conv: raw output exceeds 32-bit element offsets");
+    MVLM_REQUIRE(ctx, !a.res1 || px * a.res1_ctot < lim, "conv: residual exceeds 32-bit element offsets");
+    MVLM_REQUIRE(ctx, !a.res2 || px * a.res2_ctot < lim, "conv: residual exceeds 32-bit element offsets");
+    MVLM_REQUIRE(ctx, !a.out || px * a.out_ctot * (a.up_out ? 4 : 1) < lim, "conv: output exceeds 32-bit element offsets");
+    MVLM_REQUIRE(ctx, !a.up_out || px * a.skip_ctot * 4 < lim, "conv: skip tensor exceeds 32-bit element offsets");
     const int v = pick_variant(a);
     MVLM_REQUIRE(ctx, v >= 0, "conv: no kernel variant for this shape");
     if (variant_out) *variant_out = v;
