@@ -104,8 +104,9 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
     if constexpr (T < C::X_ITERS) {
         const int c = cb + (tid + T * 256) / C::PLANE;
         const bool ok = goff[T] != INVALID_OFF && c < a.cin;
-        const float* const base = a.in + size_t(cb) * HWin;  // wave-uniform
-        r.xv[T] = ok ? base[goff[T]] : a.in[0];
+        // wave-uniform base; one unconditional load per lane (masked lanes read a valid element)
+        const float* const base = a.in + size_t(cb < a.cin ? cb : 0) * HWin;
+        r.xv[T] = base[ok ? goff[T] : 0u];
         if (a.pre_scale != nullptr) {  // this element's BatchNorm scale / shift from the LDS copy
             const int cc = c < a.cin_pad ? c : 0;
             r.bn_s[T] = sbn[cc];

@@ -4,16 +4,21 @@
 //
 // Pipeline (all views at once, nothing returns to the host):
 //   1. transform   one thread per (view, vertex): M*v in double -> snapped window coords + z
-//   2. bin count   one thread per (view, triangle): covered pixel-centre box -> 16x16-pixel
-//                  tiles; most triangles of a 100k-face head are sub-pixel and are culled here
+//   2. classify    one thread per (view, triangle): covered pixel-centre box.  Most triangles of
+//                  a 100k-face head are sub-pixel: empty boxes are culled, boxes of <= 16 pixel
+//                  centres are resolved on the spot with a 64-bit atomicMin of the
+//                  (depth, id) key per covered pixel, larger triangles are counted into
+//                  16x16-pixel tiles and appended to the view's "big" list
 //   3. scan        one workgroup per view: exclusive prefix sum over its 256 tile counters
-//   4. bin fill    same walk as 2, triangle ids scattered into the per-tile lists
-//   5. tile raster one workgroup per (view, tile), one thread per pixel: the tile's triangle
-//                  list is staged through LDS in chunks of 256 set-up triangles (each thread
-//                  sets one up), every pixel walks the chunk (LDS broadcast reads), keeps the
-//                  winning (depth, id) key in a register - no atomics, order-independent -
+//   4. bin fill    big triangles only: ids scattered into the per-tile lists
+//   5. tile raster one workgroup per (view, tile), one thread per pixel: starts from the key the
+//                  small triangles left, stages the tile's big-triangle list through LDS in
+//                  chunks of 256 set-up triangles (each thread sets one up), every pixel walks
+//                  the chunk (LDS broadcast reads) and keeps the winning key in a register;
 //                  then shades (nearest texel, unlit) and writes its RGBD texel; a tile row is
 //                  256 contiguous bytes of the [N,256,256,4] f32 stack.
+// The key (depth bits << 32 | ~triangle id) makes the result independent of the order in which
+// atomics and tiles run: least depth wins, the later-drawn triangle wins ties (GL_LEQUAL).
 // HBM-bound by design: per view it reads the mesh once per pass and writes 1 MiB.
 #include "common.h"
 #include "raster_math.h"
@@ -37,29 +42,57 @@ __device__ inline rm_tri load_tri(const rm_vert* tvv, const int32_t* tris, int t
     return rm_setup(tvv[a], tvv[b], tvv[c]);
 }
 
-// FILL = false: count triangles per tile; FILL = true: scatter ids using the scanned offsets
-template <bool FILL>
-__global__ void bin_kernel(const rm_vert* __restrict__ tv, const int32_t* __restrict__ tris, int n_verts, int n_tris,
-                           int n_views, int* __restrict__ counts, const int* __restrict__ offsets,
-                           int* __restrict__ cursors, int* __restrict__ bins, int cap, int* __restrict__ overflow) {
+constexpr int SMALL_PIXELS = 16;  // triangles covering at most this many pixel centres skip the bins
+
+// Classify every (view, triangle): cull / resolve small ones with atomics / count big ones.
+__global__ void classify_kernel(const rm_vert* __restrict__ tv, const int32_t* __restrict__ tris, int n_verts,
+                                int n_tris, int n_views, unsigned long long* __restrict__ keys,
+                                int* __restrict__ counts, int* __restrict__ n_big, int* __restrict__ big_list) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= long(n_views) * n_tris) return;
     const int view = int(i / n_tris), t = int(i - long(view) * n_tris);
     const rm_tri tr = load_tri(tv + size_t(view) * n_verts, tris, t);
     if (!tr.valid) return;
+    const int w = tr.ix1 - tr.ix0 + 1, h = tr.iy1 - tr.iy0 + 1;
+    if (w * h <= SMALL_PIXELS) {
+        unsigned long long* kv = keys + size_t(view) * RM_SIZE * RM_SIZE;
+        for (int j = tr.iy0; j <= tr.iy1; ++j)
+            for (int ii = tr.ix0; ii <= tr.ix1; ++ii) {
+                float b0, b1, b2;
+                if (!rm_cover(&tr, ii, j, &b0, &b1, &b2)) continue;
+                const float z = rm_interp(b0, b1, b2, tr.z0, tr.z1, tr.z2);
+                if (!(z >= 0.0f && z <= 1.0f)) continue;  // near / far clip (render3d.py:136)
+                atomicMin(&kv[j * RM_SIZE + ii], (unsigned long long)rm_key(z, uint32_t(t)));
+            }
+        return;
+    }
+    big_list[size_t(view) * n_tris + atomicAdd(&n_big[view], 1)] = t;
+    const int tx0 = tr.ix0 / RM_TILE, tx1 = tr.ix1 / RM_TILE, ty0 = tr.iy0 / RM_TILE, ty1 = tr.iy1 / RM_TILE;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&counts[view * TILES + ty * RM_TILES + tx], 1);
+}
+
+// Scatter the big triangles' ids into the per-tile lists (offsets from the scan).
+__global__ void bin_fill_kernel(const rm_vert* __restrict__ tv, const int32_t* __restrict__ tris, int n_verts,
+                                int n_tris, int n_views, const int* __restrict__ n_big,
+                                const int* __restrict__ big_list, const int* __restrict__ offsets,
+                                int* __restrict__ cursors, int* __restrict__ bins, int cap,
+                                int* __restrict__ overflow) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= long(n_views) * n_tris) return;
+    const int view = int(i / n_tris), k = int(i - long(view) * n_tris);
+    if (k >= n_big[view]) return;
+    const int t = big_list[size_t(view) * n_tris + k];
+    const rm_tri tr = load_tri(tv + size_t(view) * n_verts, tris, t);
     const int tx0 = tr.ix0 / RM_TILE, tx1 = tr.ix1 / RM_TILE, ty0 = tr.iy0 / RM_TILE, ty1 = tr.iy1 / RM_TILE;
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) {
             const int tile = view * TILES + ty * RM_TILES + tx;
-            if (!FILL) {
-                atomicAdd(&counts[tile], 1);
-            } else {
-                const int pos = offsets[tile] + atomicAdd(&cursors[tile], 1);
-                if (pos < cap)
-                    bins[size_t(view) * cap + pos] = t;
-                else
-                    *overflow = 1;
-            }
+            const int pos = offsets[tile] + atomicAdd(&cursors[tile], 1);
+            if (pos < cap)
+                bins[size_t(view) * cap + pos] = t;
+            else
+                *overflow = 1;
         }
 }
 
@@ -83,7 +116,8 @@ __global__ __launch_bounds__(256) void tile_kernel(const rm_vert* __restrict__ t
                                                    const float* __restrict__ uvs, const uint8_t* __restrict__ tex,
                                                    int tex_w, int tex_h, int n_verts, const int* __restrict__ counts,
                                                    const int* __restrict__ offsets, const int* __restrict__ bins,
-                                                   int cap, float* __restrict__ out) {
+                                                   int cap, const unsigned long long* __restrict__ keys,
+                                                   float* __restrict__ out) {
     __shared__ rm_tri s_tri[256];
     __shared__ int s_id[256];
     const int view = blockIdx.x / TILES, tile = blockIdx.x % TILES;
@@ -94,7 +128,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const rm_vert* __restrict__ t
     const int n = min(counts[blockIdx.x], cap - offsets[blockIdx.x]);
     const int* list = bins + size_t(view) * cap + offsets[blockIdx.x];
 
-    uint64_t best = RM_KEY_EMPTY;
+    uint64_t best = keys[(size_t(view) * RM_SIZE + j) * RM_SIZE + i];  // what the small triangles left
     for (int base = 0; base < n; base += 256) {
         const int m = min(256, n - base);
         __syncthreads();
@@ -153,28 +187,34 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     const int cap = 4 * T + 16384;  // tile-list entries per view; larger lists raise an error
     auto* tv = static_cast<rm_vert*>(ctx->get_scratch("raster.tv", size_t(n_views) * V * sizeof(rm_vert)));
     auto* rot = static_cast<double*>(ctx->get_scratch("raster.rot", size_t(n_views) * 9 * sizeof(double)));
-    // counts | cursors | overflow in one block so a single memset clears them
+    // counts | cursors | n_big | overflow in one block so a single memset clears them
     const size_t n_ctr = size_t(n_views) * TILES;
-    auto* ctr = static_cast<int*>(ctx->get_scratch("raster.ctr", (2 * n_ctr + 4) * sizeof(int)));
+    const size_t ctr_ints = 2 * n_ctr + n_views + 4;
+    auto* ctr = static_cast<int*>(ctx->get_scratch("raster.ctr", ctr_ints * sizeof(int)));
     auto* offsets = static_cast<int*>(ctx->get_scratch("raster.off", n_ctr * sizeof(int)));
     auto* bins = static_cast<int*>(ctx->get_scratch("raster.bins", size_t(n_views) * cap * sizeof(int)));
-    MVLM_REQUIRE(ctx, tv && rot && ctr && offsets && bins, "render: scratch allocation failed");
+    auto* big_list = static_cast<int*>(ctx->get_scratch("raster.big", size_t(n_views) * T * sizeof(int)));
+    const size_t key_bytes = size_t(n_views) * RM_SIZE * RM_SIZE * sizeof(unsigned long long);
+    auto* keys = static_cast<unsigned long long*>(ctx->get_scratch("raster.keys", key_bytes));
+    MVLM_REQUIRE(ctx, tv && rot && ctr && offsets && bins && big_list && keys, "render: scratch allocation failed");
     int* counts = ctr;
     int* cursors = ctr + n_ctr;
-    int* overflow = ctr + 2 * n_ctr;
+    int* n_big = ctr + 2 * n_ctr;
+    int* overflow = n_big + n_views;
     MVLM_CHECK_HIP(ctx, hipMemcpyAsync(rot, rot_host, size_t(n_views) * 9 * sizeof(double), hipMemcpyHostToDevice,
                                        ctx->stream));
-    MVLM_CHECK_HIP(ctx, hipMemsetAsync(ctr, 0, (2 * n_ctr + 4) * sizeof(int), ctx->stream));
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(ctr, 0, ctr_ints * sizeof(int), ctx->stream));
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(keys, 0xFF, key_bytes, ctx->stream));  // RM_KEY_EMPTY everywhere
     const long nv = long(n_views) * V, nt = long(n_views) * T;
     hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, mesh->verts, V,
                        rot, n_views, tv);
-    hipLaunchKernelGGL(bin_kernel<false>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris,
-                       V, T, n_views, counts, offsets, cursors, bins, cap, overflow);
+    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris, V,
+                       T, n_views, keys, counts, n_big, big_list);
     hipLaunchKernelGGL(scan_kernel, dim3(n_views), dim3(TILES), 0, ctx->stream, counts, offsets, cap, overflow);
-    hipLaunchKernelGGL(bin_kernel<true>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris,
-                       V, T, n_views, counts, offsets, cursors, bins, cap, overflow);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris,
+                       V, T, n_views, n_big, big_list, offsets, cursors, bins, cap, overflow);
     hipLaunchKernelGGL(tile_kernel, dim3(n_views * TILES), dim3(256), 0, ctx->stream, tv, mesh->tris, mesh->uvs,
-                       mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, out_dev);
+                       mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     int h_overflow = 0;
     MVLM_CHECK_HIP(ctx, hipMemcpyAsync(&h_overflow, overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
