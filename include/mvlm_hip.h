@@ -60,6 +60,9 @@ void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* mesh);
  * out_dev f32[N,256,256,4]: RGB + depth planes in [0,1], already flipped to
  * image orientation (render3d.py:177) and divided by 255 (:191). */
 int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, int n_views, float* out_dev);
+/* mvlm_render only enqueues work; this waits for the stream and reports a deferred failure
+ * (tile lists overflowed) of the renders since the last check */
+int mvlm_render_check(mvlm_ctx* ctx);
 
 /* ---- landmark network (replaces paulsenpredictor.py:89-110, :167-217) ------------ */
 /* blob/desc: output of mvlm_amd.weights.pack_for_device (BN folded, weights as

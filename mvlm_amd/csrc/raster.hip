@@ -216,9 +216,19 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     hipLaunchKernelGGL(tile_kernel, dim3(n_views * TILES), dim3(256), 0, ctx->stream, tv, mesh->tris, mesh->uvs,
                        mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
-    int h_overflow = 0;
-    MVLM_CHECK_HIP(ctx, hipMemcpyAsync(&h_overflow, overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // the overflow flag travels to pinned host memory without stalling the stream; it is
+    // examined by mvlm_render_check (after the caller's own synchronisation point)
+    if (!ctx->render_overflow_host)
+        MVLM_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->render_overflow_host), sizeof(int)));
+    MVLM_CHECK_HIP(ctx, hipMemcpyAsync(ctx->render_overflow_host, overflow, sizeof(int), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    return 0;
+}
+
+extern "C" int mvlm_render_check(mvlm_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
     MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    MVLM_REQUIRE(ctx, h_overflow == 0, "render: per-view tile lists overflowed (mesh has too many screen-filling triangles)");
+    MVLM_REQUIRE(ctx, !ctx->render_overflow_host || *ctx->render_overflow_host == 0,
+                 "render: per-view tile lists overflowed (mesh has too many screen-filling triangles)");
     return 0;
 }

@@ -113,8 +113,11 @@ class Pipeline(abc.ABC, TimeMixin):
         rank, world = parallel.rank_world() if sharded else (0, 1)
         lo, hi = parallel.shard_range(n_total, rank, world)
 
+        from ..utils.render3d import view_rotations
+
+        rot = view_rotations(transform_stack)  # once per call: renderer and estimator share it
         t0 = time.time()
-        images = r3.render_device(mesh, transform_stack[lo:hi])
+        images = r3.render_device(mesh, transform_stack[lo:hi], rot=rot[lo:hi])
         if self.verbose:
             torch.cuda.synchronize()
         self.timings["render"] = time.time() - t0
@@ -133,7 +136,7 @@ class Pipeline(abc.ABC, TimeMixin):
         self._say("Prediction [Total]: ", self.p_time(self.timings["prediction"]))
 
         t0 = time.time()
-        starts, ends = e3.lines_device(maxima, transform_stack, 256)
+        starts, ends = e3.lines_device(maxima, transform_stack, 256, rot=rot)
         self.timings["lines"] = time.time() - t0
         self._say("Landmarks [0] - From Heatmaps: ", self.p_time(self.timings["lines"]))
 
@@ -151,7 +154,7 @@ class Pipeline(abc.ABC, TimeMixin):
             if rank == 0:
                 for lm, k in enumerate(counts_probe):
                     if k >= 3:
-                        table[lm] = np.random.choice(range(int(k)), 8, replace=True)
+                        table[lm] = np.random.randint(0, int(k), size=8)  # == np.random.choice(range(k), 8)
             table.update(parallel.broadcast_array(table if rank == 0 else None))
         out, err, _ = e3.consensus_device(maxima, starts, ends, draw_fn=draw_fn)
         error = e3.mean_error(err.cpu().numpy())
@@ -160,6 +163,7 @@ class Pipeline(abc.ABC, TimeMixin):
 
         t0 = time.time()
         landmarks = e3.project_device(mesh, out).cpu().numpy()
+        r3.check()  # deferred renderer status (the .cpu() above already synchronised)
         self.timings["project"] = time.time() - t0
         self._say("Landmarks [2] - Project to Surface: ", self.p_time(self.timings["project"]))
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")

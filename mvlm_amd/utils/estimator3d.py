@@ -40,11 +40,11 @@ class HipEstimator3D:
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         return torch, dev
 
-    def lines_device(self, landmarks_dev, transform_stack, image_size: int = 256):
+    def lines_device(self, landmarks_dev, transform_stack, image_size: int = 256, rot: np.ndarray | None = None):
         """maxima f32[NL,N,3] on device + host poses -> (starts, ends) f64[NL,N,3] on device."""
         torch, dev = self._torch()
         nl, n = int(landmarks_dev.shape[0]), int(landmarks_dev.shape[1])
-        rot = torch.from_numpy(view_rotations(transform_stack)).to(dev)
+        rot = torch.from_numpy(np.ascontiguousarray(view_rotations(transform_stack) if rot is None else rot)).to(dev)
         starts = torch.empty((nl, n, 3), dtype=torch.float64, device=dev)
         ends = torch.empty_like(starts)
         self.ctx.check(self.ctx.lib.mvlm_estimate_lines(
@@ -75,7 +75,9 @@ class HipEstimator3D:
                 if self.verbose:
                     print("Not enough points for good estimate of landmark lm_no", lm, k)
                 continue
-            draws[lm] = draw_fn(lm, k) if draw_fn is not None else np.random.choice(range(k), 8, replace=True)
+            # np.random.choice(range(k), 8, replace=True) (estimator3d.py:105) consumes the global
+            # RNG through randint(0, k, size=8); calling that directly skips building range(k)
+            draws[lm] = draw_fn(lm, k) if draw_fn is not None else np.random.randint(0, k, size=8)
         draws_dev = torch.from_numpy(draws).to(dev)
         out = torch.empty((nl, 3), dtype=torch.float64, device=dev)
         err = torch.empty((nl,), dtype=torch.float64, device=dev)

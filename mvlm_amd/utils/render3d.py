@@ -20,20 +20,38 @@ from .mesh_io import Mesh, load_obj
 __all__ = ["HipRenderer3D", "view_rotations", "upload_mesh"]
 
 
+def _view_rotation_scalar(rx, ry, rz) -> np.ndarray:
+    """One view, evaluated exactly like the reference's estimator (estimator3d.py:8-15, :57)."""
+    rx, ry, rz = (np.deg2rad(v) for v in (rx, ry, rz))
+    mx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+    my = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+    mz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
+    return (my @ mx) @ mz
+
+
 def view_rotations(transform_stack: np.ndarray) -> np.ndarray:
     """[N,>=3] (rx, ry, rz) degrees -> [N,9] float64 row-major M = Ry @ Rx @ Rz.
 
     The order is VTK's RotateY / RotateX / RotateZ pre-multiplication
     (render3d.py:140-144), which the estimator inverts (estimator3d.py:57).
+    Evaluated for all views at once; the first and last view are re-evaluated with the
+    reference's scalar formulation and, should numpy's array kernels ever round differently
+    from its scalar ones on this machine, the whole table falls back to the scalar path.
     """
     t = np.asarray(transform_stack)
-    out = np.empty((t.shape[0], 9), dtype=np.float64)
-    for i in range(t.shape[0]):
-        rx, ry, rz = (np.deg2rad(v) for v in t[i, :3])
-        mx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
-        my = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
-        mz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
-        out[i] = ((my @ mx) @ mz).ravel()
+    n = t.shape[0]
+    if n == 0:
+        return np.zeros((0, 9))
+    r = np.deg2rad(t[:, :3].astype(np.float64))
+    c, s = np.cos(r), np.sin(r)
+    mx, my, mz = np.zeros((n, 3, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3, 3))
+    mx[:, 0, 0] = 1; mx[:, 1, 1] = c[:, 0]; mx[:, 1, 2] = -s[:, 0]; mx[:, 2, 1] = s[:, 0]; mx[:, 2, 2] = c[:, 0]
+    my[:, 0, 0] = c[:, 1]; my[:, 0, 2] = s[:, 1]; my[:, 1, 1] = 1; my[:, 2, 0] = -s[:, 1]; my[:, 2, 2] = c[:, 1]
+    mz[:, 0, 0] = c[:, 2]; mz[:, 0, 1] = -s[:, 2]; mz[:, 1, 0] = s[:, 2]; mz[:, 1, 1] = c[:, 2]; mz[:, 2, 2] = 1
+    out = np.matmul(np.matmul(my, mx), mz).reshape(n, 9)
+    for i in {0, n - 1}:
+        if not np.array_equal(out[i], _view_rotation_scalar(*t[i, :3]).ravel()):
+            return np.stack([_view_rotation_scalar(*t[k, :3]).ravel() for k in range(n)])
     return out
 
 
@@ -109,19 +127,24 @@ class HipRenderer3D:
         return self.random_transform(size=self.n_views)
 
     # ---- rendering --------------------------------------------------------------------
-    def render_device(self, mesh: Mesh, transform_stack: np.ndarray):
-        """Poses -> torch.float32 [N,256,256,4] on the device (RGB + depth, /255, flipped)."""
+    def render_device(self, mesh: Mesh, transform_stack: np.ndarray, rot: np.ndarray | None = None):
+        """Poses -> torch.float32 [N,256,256,4] on the device (RGB + depth, /255, flipped).
+        Only enqueues work; ``check()`` reports a deferred failure after the caller's sync."""
         import torch
 
         n = int(transform_stack.shape[0])
         dev = torch.device("cuda", self.ctx.device)
         out = torch.empty((n, 256, 256, 4), dtype=torch.float32, device=dev)
-        rot = np.ascontiguousarray(view_rotations(transform_stack))
+        rot = np.ascontiguousarray(view_rotations(transform_stack) if rot is None else rot, dtype=np.float64)
         handle = upload_mesh(self.ctx, mesh)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         self.ctx.check(self.ctx.lib.mvlm_render(self.ctx.handle, handle, _lib.as_ptr(rot, C.c_double), n,
                                                 C.c_void_p(out.data_ptr())))
         return out
+
+    def check(self):
+        """Wait for the stream and raise if an enqueued render failed."""
+        self.ctx.check(self.ctx.lib.mvlm_render_check(self.ctx.handle))
 
     def render_3d_multi_rgb_geometry_depth(self, transform_stack, file_name):
         """Signature of render3d.py:114; returns the *unscaled* 0..255 stack like the reference."""
@@ -132,6 +155,7 @@ class HipRenderer3D:
         tt = time.time()
         stack = self.render_device(mesh, np.asarray(transform_stack))
         image_stack = (stack * 255.0).round().cpu().numpy()
+        self.check()
         if self.verbose:
             print("Render [2] - Render", f"{time.time() - tt:08.6f} s")
         return image_stack, mesh
@@ -155,6 +179,7 @@ class HipRenderer3D:
         transformation_stack = self.generate_3d_transformations()
         mesh = load_obj(file_name)
         image_stack = self.render_device(mesh, transformation_stack).cpu().numpy()
+        self.check()
         return image_stack, transformation_stack, mesh
 
     def multiview_render_device(self, file_or_mesh, transformation_stack=None):

@@ -166,18 +166,18 @@ def test_consensus_golden(golden, tag):
                         threshold_absolute=float(g[f"fuse_{tag}_cfg"][2]), verbose=False)
     s, e = e3.estimate_landmark_lines(np.zeros((lms.shape[1], 256, 256, 4), np.float32), lms, poses)
     ks = []
-    orig = np.random.choice
+    orig = np.random.randint
 
-    def rec(a, size=None, replace=True, p=None):
-        ks.append(len(a))
-        return orig(a, size, replace, p)
+    def rec(low, high=None, size=None, dtype=int):
+        ks.append(high)
+        return orig(low, high, size, dtype)
 
     np.random.seed(1)  # same seed as the generator: the host draws must coincide
-    np.random.choice = rec
+    np.random.randint = rec  # the product draws through randint(0, k, 8) == choice(range(k), 8)
     try:
         out, err = e3.estimate_landmarks_from_lines(lms, s, e)
     finally:
-        np.random.choice = orig
+        np.random.randint = orig
     np.testing.assert_array_equal(np.array(ks), g[f"fuse_{tag}_draw_k"])
     np.testing.assert_allclose(out, g[f"fuse_{tag}_out"], rtol=0, atol=1e-8)
     assert abs(err - float(g[f"fuse_{tag}_err"])) <= 1e-9 * max(1.0, abs(float(g[f"fuse_{tag}_err"])))

@@ -173,3 +173,27 @@ def test_create_pipeline_names():
         pipeline.create_pipeline("nope")
     with pytest.raises(ValueError, match="third-party"):
         pipeline.create_pipeline("MediaPipe")
+
+
+def test_rng_draw_shortcut_is_the_same_stream():
+    """np.random.choice(range(k), 8, replace=True) (estimator3d.py:105) == randint(0, k, size=8)."""
+    for k in (3, 4, 5, 17, 32, 33, 48, 64, 100, 478):
+        np.random.seed(k)
+        a = [np.random.choice(range(k), 8, replace=True) for _ in range(3)]
+        sa = np.random.get_state()[1][:8].copy()
+        np.random.seed(k)
+        b = [np.random.randint(0, k, size=8) for _ in range(3)]
+        sb = np.random.get_state()[1][:8].copy()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and np.array_equal(sa, sb)
+
+
+def test_vectorised_rotations_equal_scalar_formulation():
+    from mvlm_amd.utils.render3d import _view_rotation_scalar, view_rotations
+
+    rs = np.random.RandomState(0)
+    t = np.stack([rs.randint(-90, 90, 200), rs.randint(-180, 180, 200), rs.randint(-45, 45, 200)], 1).astype(np.float64)
+    got = view_rotations(t)
+    want = np.stack([_view_rotation_scalar(*row).ravel() for row in t])
+    np.testing.assert_array_equal(got, want)
+    t8 = np.array([[30, 15, 0, 0, 0, 0], [-30, -45, 0, 0, 0, 0]], np.float32)
+    np.testing.assert_array_equal(view_rotations(t8), np.stack([_view_rotation_scalar(*r[:3]).ravel() for r in t8]))
