@@ -113,10 +113,16 @@ def conv_slots(n_landmarks: int, in_channels: int) -> list[ConvSlot]:
     add("conv9", f, f, 3, True, None, "bn3")
     add("conv10", f, nl, 3, True, None, None)
     add("conv11", nl, nl, 3, True, None, None)
+    # conv11 runs on a nearest-2x-upsampled input (paulsenpredictor.py:428-429): every output
+    # pixel of parity (a, b) only sees a 2x2 window of the low-resolution tensor, so the layer is
+    # also packed as four 2x2 convolutions with pre-summed taps (weights.collapse_upsampled_3x3)
+    for a in (0, 1):
+        for b in (0, 1):
+            add(f"conv11.parity{a}{b}", nl, nl, 2, True, None, None)
     return slots
 
 
-N_CONV_SLOTS = 1 + 4 * 43 + 6  # 179
+N_CONV_SLOTS = 1 + 4 * 43 + 6 + 4  # 183
 
 
 def state_dict_shapes(n_landmarks: int, in_channels: int) -> dict[str, tuple[int, ...]]:
@@ -168,7 +174,7 @@ def live_conv_flops_per_view(n_landmarks: int, in_channels: int) -> float:
     sizes = conv_spatial_sizes()
     total = 0.0
     for s in conv_slots(n_landmarks, in_channels):
-        if s.present:
+        if s.present and s.ksize != 2:  # the parity slots restate conv11, already counted
             hw = sizes[s.name]
             total += 2.0 * s.cin * s.cout * s.ksize * s.ksize * hw * hw
     return total
@@ -186,4 +192,6 @@ def conv_spatial_sizes() -> dict[str, int]:
     for p, s in rb_size.items():
         for c in ("resample.2", "conv1", "conv2", "conv3"):
             sizes[f"{p}.{c}"] = s
+    for ab in ("00", "01", "10", "11"):
+        sizes[f"conv11.parity{ab}"] = 128  # evaluated on the low-resolution grid
     return sizes

@@ -56,13 +56,13 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
 extern "C" const char* mvlm_last_error(mvlm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 extern "C" int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     return 0;
 }
 
 extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -70,7 +70,7 @@ extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {
 extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
                                 const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
                                 mvlm_mesh** out) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, out, "mesh_upload: null output");
     *out = nullptr;
     MVLM_REQUIRE(ctx, verts_host && tris_host && n_verts > 0 && n_tris > 0, "mesh_upload: mesh does not contain any points");
@@ -115,12 +115,12 @@ extern "C" int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin
                            int cout, int ksize, const float* bias_host, const float* pre_scale_host,
                            const float* pre_shift_host, const float* post_scale_host, const float* post_shift_host,
                            const float* r_dev, int upsample_in, float* y_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, x_dev && w_host && y_dev, "conv2d: null pointer");
     MVLM_REQUIRE(ctx, ksize == 1 || ksize == 3, "conv2d: kernel size must be 1 or 3");
     MVLM_REQUIRE(ctx, (pre_scale_host == nullptr) == (pre_shift_host == nullptr), "conv2d: pre scale/shift come in pairs");
     MVLM_REQUIRE(ctx, (post_scale_host == nullptr) == (post_shift_host == nullptr), "conv2d: post scale/shift come in pairs");
-    const int cin_pad = (cin + 7) / 8 * 8, cout_pad = (cout + 31) / 32 * 32, taps = ksize * ksize;
+    const int cin_pad = (ksize == 1 ? (cin + 7) / 8 * 8 : (cin + 3) / 4 * 4), cout_pad = (cout + 31) / 32 * 32, taps = ksize * ksize;
     std::vector<float> blob;
     auto push = [&](size_t n) {
         const size_t off = blob.size();

@@ -324,22 +324,41 @@ struct Exec {
         }
         release(x9);
         {
-            ConvArgs a;  // conv11 over the nearest-upsampled conv10 output (:428-429)
-            a.up_in = 1;
-            Tensor xin = x10;
-            xin.S = 256;
-            if (heat) {
-                a.out = heat;
-                a.out_ctot = NL;
-                conv(SLOT_CONV5 + 5, xin, a, 256);
-            } else {
-                const int parts = mvlm_conv_amax_parts(256, 256);
-                Tensor av = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
-                Tensor ai = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
-                a.amax_val = av.p;
-                a.amax_idx = reinterpret_cast<int*>(ai.p);
-                a.amax_parts = parts;
-                conv(SLOT_CONV5 + 5, xin, a, 256);
+            // conv11 over the nearest-upsampled conv10 output (:428-429).  When the packed weights
+            // carry the four parity slots (2x2 kernels with pre-summed taps) each output parity is
+            // one launch over the 128x128 tensor: 16 instead of 36 tap evaluations per low-res pixel.
+            const int SLOT_PARITY = SLOT_CONV5 + 6;
+            const bool parity = d(SLOT_PARITY)[0] != 0 && d(SLOT_PARITY)[5] == 96;
+            const int parts1 = parity ? mvlm_conv_amax_parts(128, 128) : mvlm_conv_amax_parts(256, 256);
+            const int parts = parity ? 4 * parts1 : parts1;
+            Tensor av, ai;
+            if (!heat) {
+                av = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
+                ai = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
+            }
+            for (int pl = 0; pl < (parity ? 4 : 1); ++pl) {
+                ConvArgs a;
+                Tensor xin = x10;
+                if (parity) {
+                    a.sub_y = pl >> 1;
+                    a.sub_x = pl & 1;
+                    a.up_out = 2;
+                } else {
+                    a.up_in = 1;
+                    xin.S = 256;
+                }
+                if (heat) {
+                    a.out = heat;
+                    a.out_ctot = NL;
+                } else {
+                    a.amax_val = av.p;
+                    a.amax_idx = reinterpret_cast<int*>(ai.p);
+                    a.amax_parts = parts;
+                    a.amax_part0 = pl * parts1;
+                }
+                conv(parity ? SLOT_PARITY + pl : SLOT_CONV5 + 5, xin, a, parity ? 128 : 256);
+            }
+            if (!heat) {
                 if (!dry && !rc &&
                     mvlm_launch_amax_final(ctx, av.p, reinterpret_cast<int*>(ai.p), B, view0, n_total, NL, parts, 256,
                                            maxima))
@@ -380,9 +399,9 @@ int run_cnn(mvlm_ctx* ctx, const float* images, int n_views, const int32_t* chan
 
 extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_floats, const int32_t* desc_host,
                              int n_slots, int n_landmarks, int in_channels) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, blob_host && desc_host && n_floats > 0, "cnn_load: null weights");
-    MVLM_REQUIRE(ctx, n_slots == 1 + 4 * 43 + 6, "cnn_load: descriptor table must have 179 conv slots");
+    MVLM_REQUIRE(ctx, n_slots == 1 + 4 * 43 + 6 + 4, "cnn_load: descriptor table must have 183 conv slots");
     MVLM_REQUIRE(ctx, n_landmarks > 0 && in_channels >= 1 && in_channels <= 4, "cnn_load: bad landmark / channel count");
     CnnState& st = ctx->cnn;
     MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
@@ -396,8 +415,8 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
     for (int s = 0; s < n_slots; ++s) {
         const int32_t* r = &st.desc[size_t(s) * MVLM_CONV_DESC_INTS];
         if (!r[0]) continue;
-        MVLM_REQUIRE(ctx, r[1] > 0 && r[2] > 0 && (r[3] == 1 || r[3] == 3), "cnn_load: bad conv shape");
-        MVLM_REQUIRE(ctx, r[4] % 8 == 0 && r[4] >= r[1] && r[5] % 32 == 0 && r[5] >= r[2], "cnn_load: bad padding");
+        MVLM_REQUIRE(ctx, r[1] > 0 && r[2] > 0 && r[3] >= 1 && r[3] <= 3, "cnn_load: bad conv shape");
+        MVLM_REQUIRE(ctx, r[4] % 4 == 0 && r[4] >= r[1] && r[5] % 32 == 0 && r[5] >= r[2], "cnn_load: bad padding");
         const size_t wsz = size_t(r[3]) * r[3] * r[4] * r[5];
         MVLM_REQUIRE(ctx, r[6] >= 0 && size_t(r[6]) + wsz <= n_floats, "cnn_load: weight offset out of range");
         const int offs[5] = {r[7], r[8], r[9], r[10], r[11]};
@@ -406,7 +425,7 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
             MVLM_REQUIRE(ctx, offs[k] < 0 || size_t(offs[k]) + lens[k] <= n_floats, "cnn_load: vector offset out of range");
     }
     MVLM_REQUIRE(ctx, st.desc[1] == in_channels, "cnn_load: conv1 input channels != in_channels");
-    MVLM_REQUIRE(ctx, st.desc[size_t(n_slots - 1) * MVLM_CONV_DESC_INTS + 2] == n_landmarks,
+    MVLM_REQUIRE(ctx, st.desc[size_t(1 + 4 * 43 + 5) * MVLM_CONV_DESC_INTS + 2] == n_landmarks,
                  "cnn_load: conv11 output channels != n_landmarks");
     MVLM_CHECK_HIP(ctx, hipMalloc(&st.blob, n_floats * sizeof(float)));
     MVLM_CHECK_HIP(ctx, hipMemcpy(st.blob, blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -417,7 +436,7 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
 }
 
 extern "C" size_t mvlm_cnn_workspace_bytes(mvlm_ctx* ctx, int batch) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->mu);  // host-only planning: no device work, 0 = failure
     if (!ctx->cnn.loaded || batch <= 0) return 0;
     Exec ex(ctx, batch, nullptr, 0, true);
     const int sel4[4] = {0, 0, 0, 0};
@@ -427,26 +446,27 @@ extern "C" size_t mvlm_cnn_workspace_bytes(mvlm_ctx* ctx, int batch) {
 
 extern "C" int mvlm_cnn_maxima(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
                                float* maxima_dev, void* workspace_dev, size_t workspace_bytes, int batch) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, maxima_dev && chan_sel_host, "cnn_maxima: null output / selector");
     return run_cnn(ctx, images_dev, n_views, chan_sel_host, maxima_dev, nullptr, workspace_dev, workspace_bytes, batch);
 }
 
 extern "C" int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
                                  float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, heat_dev && chan_sel_host, "cnn_heatmaps: null output / selector");
     return run_cnn(ctx, images_dev, n_views, chan_sel_host, nullptr, heat_dev, workspace_dev, workspace_bytes, batch);
 }
 
 extern "C" int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     ctx->cnn.profiling = enabled != 0;
     return 0;
 }
 
 extern "C" int mvlm_cnn_get_profile(mvlm_ctx* ctx, int32_t* slot, int32_t* variant, double* flops, float* ms, int cap) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->mu);  // returns a record count, -1 on failure
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
     CnnState& st = ctx->cnn;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
     int n = 0;

@@ -20,6 +20,12 @@
         }                                                                                    \
     } while (0)
 
+// every entry point: serialise callers of this context and make its GPU the calling thread's
+// current device (a process may hold contexts for several GPUs)
+#define MVLM_ENTER(ctx)                               \
+    std::lock_guard<std::mutex> _mvlm_lock((ctx)->mu); \
+    MVLM_CHECK_HIP(ctx, hipSetDevice((ctx)->device))
+
 #define MVLM_REQUIRE(ctx, cond, msg)                                                         \
     do {                                                                                     \
         if (!(cond)) {                                                                       \
@@ -58,13 +64,17 @@ struct ConvArgs {
     int raw_ctot = 0, raw_coff = 0;
     float* out = nullptr;  // v + residual
     int out_ctot = 0, out_coff = 0;
-    int up_out = 0;  // 1: out is [B][out_ctot][2H][2W]; each value is written to its 2x2 block, + skip there
+    // 1: out is [B][out_ctot][2H][2W]; each value is written to its 2x2 block, + skip there
+    // 2: out is [B][out_ctot][2H][2W]; the value goes to pixel (2y + sub_y, 2x + sub_x) only
+    int up_out = 0;
+    int sub_y = 0, sub_x = 0;  // up_out == 2 / ksize == 2: output parity = 2x2 window offset in the halo tile
     const float* skip = nullptr;
     int skip_ctot = 0, skip_coff = 0;
     // fused per-(image, channel) argmax partials (conv11): [B][cout][n_part]
     float* amax_val = nullptr;
     int* amax_idx = nullptr;
-    int amax_parts = 0;
+    int amax_parts = 0;   // partials per (image, channel) in the buffers
+    int amax_part0 = 0;   // first partial this launch writes (parity launches share one buffer)
 };
 
 struct ConvProfileRec {

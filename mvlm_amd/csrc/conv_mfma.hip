@@ -57,7 +57,7 @@ template <int COUT_T_, int TW_, int TRI_, int NIMG_, int KS_, int CK_>
 struct Cfg {
     static constexpr int COUT_T = COUT_T_, TW = TW_, TRI = TRI_, NIMG = NIMG_, KS = KS_, CK = CK_;
     static constexpr int TAPS = KS * KS;
-    static constexpr int HALO = KS / 2;
+    static constexpr int HALO = KS == 1 ? 0 : 1;  // KS == 2: a 2x2 window inside the 3x3 halo tile
     static constexpr int PW = TW + 2 * HALO;
     static constexpr int PH = TRI + 2 * HALO;
     static constexpr int PLANE = NIMG * PH * PW;  // floats per channel in sX
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         const int rr = p / C::TW;
         const int yl = rr % C::TRI;
         const int img = rr / C::TRI;
-        pixoff[n] = (img * C::PH + yl) * C::PW + x + half * C::PLANE;
+        pixoff[n] = (img * C::PH + yl) * C::PW + x + half * C::PLANE + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0);
     }
     const int woff = C::XT_PAD + half * C::COUT_T + l31;
 
@@ -346,6 +346,11 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         if (!a.up_out) {
             o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * HW + pix;
             o_skip[n] = 0;
+        } else if (a.up_out == 2) {
+            const unsigned o2 = unsigned(2 * y + a.sub_y) * unsigned(2 * W) + unsigned(2 * x + a.sub_x);
+            o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * (4u * HW) + o2;
+            o_skip[n] = 0;
+            ppix[n] = int(o2);  // the argmax runs over full-resolution pixel indices
         } else {
             const unsigned o2 = unsigned(2 * y) * unsigned(2 * W) + unsigned(2 * x);
             o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * (4u * HW) + o2;
@@ -424,10 +429,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 for (int e = 0; e < GE; ++e) vals[e] += resv[g & 1][e];
             }
             if (a.out) {
-                if (!a.up_out) {
+                if (a.up_out != 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float* const p = a.out + size_t(cs0 + j) * HW;
+                        float* const p = a.out + size_t(cs0 + j) * HW * (a.up_out ? 4 : 1);
 #pragma unroll
                         for (int n = 0; n < C::NT; ++n)
                             if (okc[j] && lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                     best_i = better ? oi : best_i;
                 }
                 if (l31 == 0 && co < a.cout && b0 < a.B) {
-                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + (size_t(ty) * tiles_x + tx) * 4 + wave;
+                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
                     a.amax_val[o] = best_v;
                     a.amax_idx[o] = best_i;
                 }
@@ -515,7 +520,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)         \
     X(8, "conv3x3_c128_t4x32", Cfg<128, 32, 4, 1, 3, 4>)        \
     X(9, "conv3x3_c64_t4x32", Cfg<64, 32, 4, 1, 3, 4>)          \
-    X(10, "conv3x3_c64_t8x32", Cfg<64, 32, 8, 1, 3, 4>)
+    X(10, "conv3x3_c64_t8x32", Cfg<64, 32, 8, 1, 3, 4>)         \
+    X(11, "conv2x2_c96_t8x32", Cfg<96, 32, 8, 1, 2, 4>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -528,8 +534,9 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
     MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
     if (a.amax_val) {
         MVLM_REQUIRE(ctx, C::NIMG == 1, "conv: fused argmax needs one image per tile");
-        MVLM_REQUIRE(ctx, a.amax_parts == tiles_x * tiles_y * 4, "conv: argmax partial count mismatch");
-        MVLM_REQUIRE(ctx, !a.res1 && !a.post_scale && !a.up_out, "conv: fused argmax expects a plain conv + bias layer");
+        MVLM_REQUIRE(ctx, a.amax_part0 >= 0 && a.amax_part0 + tiles_x * tiles_y * 4 <= a.amax_parts,
+                     "conv: argmax partial range mismatch");
+        MVLM_REQUIRE(ctx, !a.res1 && !a.post_scale && a.up_out != 1, "conv: fused argmax expects a plain conv + bias layer");
     }
     const long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
@@ -537,13 +544,13 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
     if (!attr_set) {
         MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
-        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS == 3)
+        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS != 1)
             MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
         attr_set = true;
     }
     if (a.amax_val) {
-        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS == 3) {
+        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS != 1) {
             hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream,
                                a, tiles_x, tiles_y, cout_tiles);
         } else {
@@ -564,6 +571,7 @@ int pick_variant(const ConvArgs& a) {
         return e && std::string(e) == "small";
     }();
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
+    if (a.ksize == 2) return (a.W >= 32 && a.cout_pad == 96 && a.H % 8 == 0) ? 11 : -1;
     if (a.W >= 32) {
         // two workgroups fit a CU: below ~512 workgroups the 128-pixel tiles fill the chip better
         const long px = long(a.B) * a.H * a.W;
@@ -607,14 +615,15 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     MVLM_REQUIRE(ctx, a.in && a.w && a.B > 0 && a.H > 0 && a.W > 0, "conv: null input / weights or empty shape");
     MVLM_REQUIRE(ctx, a.H == a.W, "conv: square feature maps only");
     MVLM_REQUIRE(ctx, !a.up_in || (a.H % 2 == 0), "conv: upsampled input needs even size");
-    MVLM_REQUIRE(ctx, !a.up_out || a.skip, "conv: up_out needs a skip tensor");
+    MVLM_REQUIRE(ctx, a.up_out != 1 || a.skip, "conv: up_out needs a skip tensor");
+    MVLM_REQUIRE(ctx, a.ksize != 2 || ((a.sub_y | a.sub_x) & ~1) == 0, "conv: 2x2 window offset must be 0 or 1");
     const double px = double(a.B) * a.H * a.W, lim = 4294967295.0;
     MVLM_REQUIRE(ctx, px * a.in_ctot < lim, "conv: input tensor exceeds 32-bit element offsets (lower the batch)");
     MVLM_REQUIRE(ctx, !a.out_raw || px * a.raw_ctot < lim, "conv: raw output exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, !a.res1 || px * a.res1_ctot < lim, "conv: residual exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, !a.res2 || px * a.res2_ctot < lim, "conv: residual exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, !a.out || px * a.out_ctot * (a.up_out ? 4 : 1) < lim, "conv: output exceeds 32-bit element offsets");
-    MVLM_REQUIRE(ctx, !a.up_out || px * a.skip_ctot * 4 < lim, "conv: skip tensor exceeds 32-bit element offsets");
+    MVLM_REQUIRE(ctx, a.up_out != 1 || px * a.skip_ctot * 4 < lim, "conv: skip tensor exceeds 32-bit element offsets");
     const int v = pick_variant(a);
     MVLM_REQUIRE(ctx, v >= 0, "conv: no kernel variant for this shape");
     if (variant_out) *variant_out = v;

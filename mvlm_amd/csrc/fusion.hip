@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ st
 
 extern "C" int mvlm_estimate_lines(mvlm_ctx* ctx, const float* maxima_dev, const double* rot_dev, int n_views,
                                    int n_landmarks, int image_size, double* starts_dev, double* ends_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, maxima_dev && rot_dev && starts_dev && ends_dev, "estimate_lines: null pointer");
     MVLM_REQUIRE(ctx, n_views > 0 && n_landmarks > 0 && image_size > 0, "estimate_lines: empty problem");
     const int total = n_views * n_landmarks;
@@ -279,7 +279,7 @@ extern "C" int mvlm_estimate_lines(mvlm_ctx* ctx, const float* maxima_dev, const
 
 extern "C" int mvlm_consensus_mask(mvlm_ctx* ctx, const float* maxima_dev, int n_views, int n_landmarks, int mode,
                                    double q, double thr, uint8_t* mask_dev, int32_t* count_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, maxima_dev && mask_dev && count_dev, "consensus_mask: null pointer");
     MVLM_REQUIRE(ctx, n_views > 0 && n_views <= MAX_VIEWS && n_landmarks > 0, "consensus_mask: 1..1024 views supported");
     MVLM_REQUIRE(ctx, mode == MVLM_MODE_QUANTILE || mode == MVLM_MODE_ABSOLUTE,
@@ -294,7 +294,7 @@ extern "C" int mvlm_consensus_mask(mvlm_ctx* ctx, const float* maxima_dev, int n
 extern "C" int mvlm_consensus_solve(mvlm_ctx* ctx, const double* starts_dev, const double* ends_dev,
                                     const uint8_t* mask_dev, const int32_t* count_dev, const int32_t* draws_dev,
                                     int n_views, int n_landmarks, double* out_dev, double* err_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, starts_dev && ends_dev && mask_dev && draws_dev && out_dev && err_dev,
                  "consensus_solve: null pointer");
     MVLM_REQUIRE(ctx, n_views > 0 && n_views <= MAX_VIEWS && n_landmarks > 0, "consensus_solve: 1..1024 views supported");

@@ -199,7 +199,7 @@ int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int 
 
 extern "C" int mvlm_heatmap_maxima(mvlm_ctx* ctx, const float* heat_dev, int n_views, int n_landmarks, int size,
                                    int method, float* out_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, heat_dev && out_dev && n_views > 0 && n_landmarks > 0 && size > 0, "heatmap_maxima: bad arguments");
     MVLM_REQUIRE(ctx, method == MVLM_MAXIMA_SIMPLE || method == MVLM_MAXIMA_MOMENT, "heatmap_maxima: unknown method");
     hipLaunchKernelGGL(heatmap_maxima_kernel, dim3(n_views * n_landmarks), dim3(256), 0, ctx->stream, heat_dev, n_views,

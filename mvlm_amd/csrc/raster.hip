@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const rm_vert* __restrict__ t
 }  // namespace
 
 extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, int n_views, float* out_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, mesh && rot_host && out_dev && n_views > 0, "render: bad arguments");
     MVLM_REQUIRE(ctx, mesh->n_verts > 0 && mesh->n_tris > 0, "render: empty mesh");
     const int V = mesh->n_verts, T = mesh->n_tris;
@@ -226,7 +226,7 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
 }
 
 extern "C" int mvlm_render_check(mvlm_ctx* ctx) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MVLM_REQUIRE(ctx, !ctx->render_overflow_host || *ctx->render_overflow_host == 0,
                  "render: per-view tile lists overflowed (mesh has too many screen-filling triangles)");

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
 
 extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* pts_dev, int n_points,
                                        double* out_dev) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, mesh && pts_dev && out_dev && n_points > 0, "project_to_surface: bad arguments");
     MVLM_REQUIRE(ctx, mesh->n_tris > 0, "project_to_surface: empty mesh");
     hipLaunchKernelGGL(project_kernel, dim3(n_points), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris, mesh->n_tris,

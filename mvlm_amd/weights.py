@@ -17,7 +17,7 @@ import numpy as np
 
 from . import arch
 
-CIN_ALIGN = 8    # K-chunk of the conv kernel (channels per LDS stage)
+CIN_ALIGN = 4    # smallest K-chunk of the conv kernel (channels per LDS stage)
 COUT_ALIGN = 32  # one MFMA 32x32 tile of output channels
 DESC_INTS = 12   # int32 fields per conv slot in the descriptor table
 
@@ -89,6 +89,25 @@ def fold_bn(sd: dict[str, np.ndarray], prefix: str) -> tuple[np.ndarray, np.ndar
     return scale, shift
 
 
+def collapse_upsampled_3x3(w: np.ndarray, a: int, b: int) -> np.ndarray:
+    """3x3 kernel applied after nearest 2x upsampling == 2x2 kernel on the low-res tensor.
+
+    Output pixel (2i+a, 2j+b) reads upsampled rows 2i+a-1..2i+a+1, i.e. low-res rows
+    {i-1, i, i} for a = 0 and {i, i, i+1} for a = 1 (same for columns), so the taps that land on
+    the same low-res pixel are summed (in float64, rounded once).  w [cout,cin,3,3] ->
+    [cout,cin,2,2] over low-res rows (i-1+a, i+a), columns (j-1+b, j+b).
+    """
+    groups = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    w64 = w.astype(np.float64)
+    out = np.zeros(w.shape[:2] + (2, 2), np.float64)
+    for ty, rows in enumerate(groups[a]):
+        for tx, cols in enumerate(groups[b]):
+            for r in rows:
+                for c in cols:
+                    out[:, :, ty, tx] += w64[:, :, r, c]
+    return out.astype(np.float32)
+
+
 def _round_up(x: int, a: int) -> int:
     return (x + a - 1) // a * a
 
@@ -128,14 +147,20 @@ def pack_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: in
         row[4:6] = (cin_pad, cout_pad)
         if not s.present:
             continue
-        w = sd[f"{s.name}.weight"].astype(np.float32)  # [cout, cin, k, k]
+        if s.ksize == 2:  # "conv11.parityAB"
+            base, par = s.name.rsplit(".parity", 1)
+            w = collapse_upsampled_3x3(sd[f"{base}.weight"].astype(np.float32), int(par[0]), int(par[1]))
+            bias_key = f"{base}.bias"
+        else:
+            w = sd[f"{s.name}.weight"].astype(np.float32)  # [cout, cin, k, k]
+            bias_key = f"{s.name}.bias"
         k = s.ksize
         wp = np.zeros((k * k, cin_pad, cout_pad), np.float32)
         wp[:, : s.cin, : s.cout] = w.transpose(2, 3, 1, 0).reshape(k * k, s.cin, s.cout)
         row[6] = push(wp)
         if s.has_bias:
             b = np.zeros(cout_pad, np.float32)
-            b[: s.cout] = sd[f"{s.name}.bias"]
+            b[: s.cout] = sd[bias_key]
             row[7] = push(b)
         if s.pre_bn is not None:
             sc, sh = fold_bn(sd, s.pre_bn)

@@ -109,7 +109,7 @@ def test_packed_weights_reproduce_conv(tmp_path):
     blob, desc = weights.pack_for_device(sd, 73, 3)
     assert desc.shape == (arch.N_CONV_SLOTS, weights.DESC_INTS)
     slots = arch.conv_slots(73, 3)
-    assert sum(s.present for s in slots) == 138
+    assert sum(s.present and s.ksize != 2 for s in slots) == 138  # + 4 parity restatements of conv11
     s = next(s for s in slots if s.name == "conv4.conv1")
     row = desc[s.index]
     cin_pad, cout_pad = int(row[4]), int(row[5])
@@ -197,3 +197,23 @@ def test_vectorised_rotations_equal_scalar_formulation():
     np.testing.assert_array_equal(got, want)
     t8 = np.array([[30, 15, 0, 0, 0, 0], [-30, -45, 0, 0, 0, 0]], np.float32)
     np.testing.assert_array_equal(view_rotations(t8), np.stack([_view_rotation_scalar(*r[:3]).ravel() for r in t8]))
+
+
+def test_collapsed_upsampled_conv_equals_conv_of_upsampled():
+    """conv3x3(nearest_upsample2x(x)) == four 2x2 convolutions of x, one per output parity."""
+    from mvlm_amd.weights import collapse_upsampled_3x3
+
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.standard_normal((2, 5, 6, 7))).double()
+    w = rs.standard_normal((4, 5, 3, 3)).astype(np.float32)
+    want = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"),
+                                      torch.from_numpy(w).double(), None, 1, 1)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
+    got = torch.zeros_like(want)
+    for a in (0, 1):
+        for b in (0, 1):
+            w2 = torch.from_numpy(collapse_upsampled_3x3(w, a, b)).double()
+            # window rows (i-1+a, i+a), cols (j-1+b, j+b) of x == rows (i+a, i+a+1) of the padded tensor
+            y = torch.nn.functional.conv2d(xp[:, :, a:a + 7, b:b + 8], w2)
+            got[:, :, a::2, b::2] = y
+    assert torch.allclose(got, want, atol=1e-5)
