@@ -60,6 +60,11 @@ void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* mesh);
  * out_dev f32[N,256,256,4]: RGB + depth planes in [0,1], already flipped to
  * image orientation (render3d.py:177) and divided by 255 (:191). */
 int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, int n_views, float* out_dev);
+/* what the RGB planes hold: 0 = unlit white x nearest texel, exactly what the reference renders
+ * (utils3d.py:58-64); 1 = build-defined "geometry" shading (flat two-sided head light, grey in all
+ * three planes) for models trained on geometry renderings - the reference's renderer has no such
+ * mode, parity unpinned. */
+int mvlm_set_render_shading(mvlm_ctx* ctx, int shading);
 /* mvlm_render only enqueues work; this waits for the stream and reports a deferred failure
  * (tile lists overflowed) of the renders since the last check */
 int mvlm_render_check(mvlm_ctx* ctx);

@@ -1,0 +1,66 @@
+"""Command line front end: ``python -m mvlm_amd -p <obj or folder> [-o out] [-n views]``.
+
+Same behaviour as the reference's ``main.py`` (:9-67): collect ``*.obj`` files, run every
+available pipeline over them and write ``<stem>_<pipeline>.txt`` (comma-separated [NL,3]
+landmarks, ``np.savetxt(..., delimiter=",")``, main.py:62).  Only the pipelines whose 2-D
+predictor this build ships are looped ("bu3dfe", "dtu3d"); the viewer flags of the reference
+(``--visualize-iter`` / ``--visualize-img``) need VTK and are not available.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+
+def main(argv=None) -> int:
+    parser = argparse.ArgumentParser(prog="python -m mvlm_amd")
+    parser.add_argument("-p", "--path", type=str, required=True)
+    parser.add_argument("-o", "--out", type=str, required=False)
+    parser.add_argument("-n", "--n-views", type=int, default=8, help="Number of views to render")
+    parser.add_argument("--visualize-method", action="store_true", help="Dump the rendered views as PNG next to the mesh")
+    parser.add_argument("--pipelines", type=str, default="bu3dfe,dtu3d")
+    parser.add_argument("--weights", type=str, default=None,
+                        help='checkpoint path, or "synthetic[:seed]" (no checkpoint is reachable offline)')
+    parser.add_argument("--device", type=int, default=0)
+    args = parser.parse_args(argv)
+    if args.out is None:
+        args.out = args.path
+    input_path, path_to_out = Path(args.path), Path(args.out)
+    if not input_path.exists():
+        print(f"{input_path.as_posix()} does not exist.")
+        return 1
+    if input_path.is_file():
+        if input_path.suffix.lower() != ".obj":
+            print(f"{input_path.as_posix()} is not an .obj file.")
+            return 1
+        obj_files = [input_path]
+        if args.out == args.path:
+            path_to_out = input_path.parent
+    else:
+        obj_files = sorted(input_path.glob("*.obj"))
+        if len(obj_files) == 0:
+            print("Given folder does not contain any .obj files.")
+            return 1
+    path_to_out.mkdir(parents=True, exist_ok=True)
+
+    from . import pipeline
+
+    for pname in [p for p in args.pipelines.split(",") if p]:
+        print(f"Pipeline: {pname}")
+        dm = pipeline.create_pipeline(pname, render_image_stack=args.visualize_method, n_views=args.n_views,
+                                      weights=args.weights, device=args.device)
+        for file in obj_files:
+            print(f"Current file: {file}")
+            landmarks = dm.predict_one_file(file)
+            if landmarks is None:
+                print(f"Landmarks for {file} could not be predicted -> skipping file [{file.stem}] for pipeline {pname}")
+                continue
+            np.savetxt((path_to_out / f"{file.stem}_{pname}.txt").as_posix(), landmarks, delimiter=",")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

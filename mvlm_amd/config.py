@@ -68,6 +68,9 @@ class MVLMConfig:
         pipe.estimator_3d.mode = self.filter_view_lines
         pipe.estimator_3d.threshold_quantile = self.heatmap_max_quantile
         pipe.estimator_3d.threshold_absolute = self.heatmap_abs_threshold
+        pipe.pre_align = dict(self.pre_align)
+        if "geometry" in self.image_channels:
+            pipe.renderer_3d.shading = "geometry"  # plane 0 carries the shaded geometry
         return pipe
 
 

@@ -110,6 +110,7 @@ struct mvlm_ctx {
     CnnState cnn;
     // grow-only internal scratch (raster bins, transformed vertices, small staging)
     std::map<std::string, std::pair<void*, size_t>> scratch;
+    int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render
     int fail(const std::string& m) {
         err = m;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const rm_vert* __restrict__ t
                                                    int tex_w, int tex_h, int n_verts, const int* __restrict__ counts,
                                                    const int* __restrict__ offsets, const int* __restrict__ bins,
                                                    int cap, const unsigned long long* __restrict__ keys,
-                                                   float* __restrict__ out) {
+                                                   int shading, float* __restrict__ out) {
     __shared__ rm_tri s_tri[256];
     __shared__ int s_id[256];
     const int view = blockIdx.x / TILES, tile = blockIdx.x % TILES;
@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256) void tile_kernel(const rm_vert* __restrict__ t
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
         rm_cover(&tr, i, j, &b0, &b1, &b2);
         float r = 255.f, g = 255.f, bl = 255.f;
-        if (tex && uvs) {
+        if (shading == 1) {
+            r = g = bl = float(rm_geometry_u8(&tr));
+        } else if (tex && uvs) {
             const float u = rm_interp(b0, b1, b2, uvs[2 * a], uvs[2 * b], uvs[2 * c]);
             const float v = rm_interp(b0, b1, b2, uvs[2 * a + 1], uvs[2 * b + 1], uvs[2 * c + 1]);
             const uint8_t* tp = tex + size_t(rm_texel(u, v, tex_w, tex_h)) * 3;
@@ -214,7 +216,7 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris,
                        V, T, n_views, n_big, big_list, offsets, cursors, bins, cap, overflow);
     hipLaunchKernelGGL(tile_kernel, dim3(n_views * TILES), dim3(256), 0, ctx->stream, tv, mesh->tris, mesh->uvs,
-                       mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys, out_dev);
+                       mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys, ctx->render_shading, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     // the overflow flag travels to pinned host memory without stalling the stream; it is
     // examined by mvlm_render_check (after the caller's own synchronisation point)
@@ -230,5 +232,12 @@ extern "C" int mvlm_render_check(mvlm_ctx* ctx) {
     MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MVLM_REQUIRE(ctx, !ctx->render_overflow_host || *ctx->render_overflow_host == 0,
                  "render: per-view tile lists overflowed (mesh has too many screen-filling triangles)");
+    return 0;
+}
+
+extern "C" int mvlm_set_render_shading(mvlm_ctx* ctx, int shading) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, shading == 0 || shading == 1, "render: shading must be 0 (unlit texture) or 1 (geometry)");
+    ctx->render_shading = shading;
     return 0;
 }

@@ -154,6 +154,21 @@ RM_FN int rm_depth_u8(float z) {
     return (256 - t) & 255;
 }
 
+/* Build-defined "geometry" plane (absent from the reference renderer): flat
+ * two-sided head-light shading |n.z| / |n| of the winning triangle in view space, as 0..255.
+ * The normal comes from the snapped window coordinates (1/256 px) and the z-buffer values
+ * converted to the same unit: 1 z-buffer unit = 1500 model units = 1500 * 256/300 * 256 steps. */
+RM_FN int rm_geometry_u8(const rm_tri* t) {
+    const float kz = -327680.0f;
+    const float ax = (float)(t->X1 - t->X0), ay = (float)(t->Y1 - t->Y0), az = (t->z1 - t->z0) * kz;
+    const float bx = (float)(t->X2 - t->X0), by = (float)(t->Y2 - t->Y0), bz = (t->z2 - t->z0) * kz;
+    const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    if (!(len > 0.0f)) return 0;
+    const float s = fabsf(nz) / len;
+    return (int)(s * 255.0f + 0.5f);
+}
+
 /* nearest texel with GL_REPEAT wrapping; image rows are stored top row first while
  * v = 0 is the bottom of the image (vtkJPEGReader / OBJ convention) */
 RM_FN int rm_texel(float u, float v, int tw, int th) {

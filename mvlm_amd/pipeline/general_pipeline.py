@@ -63,6 +63,9 @@ class Pipeline(abc.ABC, TimeMixin):
         self.verbose = verbose
         self.timings: dict[str, float] = {}
         self.last_error: float | None = None
+        # optional "pre-align" block of a Deep-MVLM config (mvlm_amd/utils/prealign.py); the
+        # reference's live pipeline has none (it renders the mesh as-is)
+        self.pre_align: dict | None = None
 
         self.renderer_3d = HipRenderer3D(image_size=(256, 256), offscreen=offscreen, n_views=n_views, device=device,
                                          verbose=verbose)
@@ -201,7 +204,17 @@ class Pipeline(abc.ABC, TimeMixin):
         else:
             poses = self.renderer_3d.generate_3d_transformations()
         self.timings["load"] = self.toc()
+        matrix = None
+        if self.pre_align and any(self.pre_align.get(k) for k in ("align_center_of_mass", "rot_x", "rot_y", "rot_z")) \
+                or (self.pre_align and float(self.pre_align.get("scale", 1)) != 1.0):
+            from ..utils.prealign import apply_prealign
+
+            mesh, matrix = apply_prealign(mesh, self.pre_align)
         landmarks, _ = self.predict_mesh_device(mesh, poses)
+        if matrix is not None:
+            from ..utils.prealign import landmarks_to_original_space
+
+            landmarks = landmarks_to_original_space(landmarks, matrix)
         return landmarks
 
     # ---- the reference's numpy slot protocol (general_pipeline.py:83-108) ----------------

@@ -92,7 +92,7 @@ class HipRenderer3D:
                  min_x_angle: int = -40, max_x_angle: int = 40, min_y_angle: int = -80, max_y_angle: int = 80,
                  min_z_angle: int = -20, max_z_angle: int = 20, min_scale: float = 1.4, max_scale: float = 1.9,
                  min_tx: int = -20, max_tx: int = 20, min_ty: int = -20, max_ty: int = 20, device: int = 0,
-                 verbose: bool = True):
+                 verbose: bool = True, shading: str = "texture"):
         if tuple(image_size) != (256, 256):
             raise ValueError("the HIP renderer is built for 256x256 views (general_pipeline.py:57)")
         self.n_views = n_views
@@ -107,6 +107,10 @@ class HipRenderer3D:
         self.slack = 5
         self.side_length = max([150 - (-150), 150 - (-150)]) * 1.0 / 2  # render3d.py:50
         self.verbose = verbose
+        if shading not in ("texture", "geometry"):
+            raise ValueError("shading must be 'texture' (the reference's unlit render) or 'geometry'")
+        # "geometry": build-defined shaded plane for models trained on geometry renderings
+        self.shading = shading
         self.ctx = _lib.get_context(device)
 
     # ---- pose table (render3d.py:79-112) ----------------------------------------------
@@ -138,6 +142,7 @@ class HipRenderer3D:
         rot = np.ascontiguousarray(view_rotations(transform_stack) if rot is None else rot, dtype=np.float64)
         handle = upload_mesh(self.ctx, mesh)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.check(self.ctx.lib.mvlm_set_render_shading(self.ctx.handle, 1 if self.shading == "geometry" else 0))
         self.ctx.check(self.ctx.lib.mvlm_render(self.ctx.handle, handle, _lib.as_ptr(rot, C.c_double), n,
                                                 C.c_void_p(out.data_ptr())))
         return out

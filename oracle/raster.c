@@ -72,8 +72,19 @@ static int32_t fdiv(int32_t a, int32_t b) {
  * verts f32[V,3], uvs f32[V,2] or NULL, tris i32[T,3], tex u8[th,tw,3] or NULL,
  * rot f64[n_views,9] -> out f32[n_views,256,256,4]
  */
+/* build-defined geometry plane: |n.z|/|n| of the triangle in view space */
+static int geometry_u8(SV a, SV b, SV c) {
+    const float kz = -327680.0f; /* z-buffer unit -> 1/256 pixel: -1500 * 256/300 * 256 */
+    float ax = (float)(b.x - a.x), ay = (float)(b.y - a.y), az = (b.z - a.z) * kz;
+    float bx = (float)(c.x - a.x), by = (float)(c.y - a.y), bz = (c.z - a.z) * kz;
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    if (!(len > 0.0f)) return 0;
+    return (int)((fabsf(nz) / len) * 255.0f + 0.5f);
+}
+
 int oracle_render(const float* verts, const float* uvs, int n_verts, const int32_t* tris, int n_tris,
-                  const uint8_t* tex, int th, int tw, const double* rot, int n_views, float* out) {
+                  const uint8_t* tex, int th, int tw, const double* rot, int n_views, int shading, float* out) {
     SV* sv = (SV*)malloc(sizeof(SV) * (size_t)n_verts);
     float* zbuf = (float*)malloc(sizeof(float) * N * N);
     int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * N * N);
@@ -144,7 +155,9 @@ int oracle_render(const float* verts, const float* uvs, int n_verts, const int32
                     int ia = tris[3 * t], ib = tris[3 * t + 1], ic = tris[3 * t + 2];
                     if (flipped) { int s = ib; ib = ic; ic = s; }
                     z = zbuf[p];
-                    if (tex && uvs) {
+                    if (shading == 1) {
+                        r = g = bl = (float)geometry_u8(sv[ia], sv[ib], sv[ic]);
+                    } else if (tex && uvs) {
                         float b0 = bary[3 * p], b1 = bary[3 * p + 1], b2 = bary[3 * p + 2];
                         float u = (b0 * uvs[2 * ia] + b1 * uvs[2 * ib]) + b2 * uvs[2 * ic];
                         float v = (b0 * uvs[2 * ia + 1] + b1 * uvs[2 * ib + 1]) + b2 * uvs[2 * ic + 1];

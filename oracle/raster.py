@@ -32,7 +32,7 @@ def _load():
     return _lib
 
 
-def multiview_render(verts, tris, uvs, texture, transform_stack) -> np.ndarray:
+def multiview_render(verts, tris, uvs, texture, transform_stack, shading: str = "texture") -> np.ndarray:
     """-> image_stack [N,256,256,4] float32 in [0,1] (render3d.py:179-193 output)."""
     lib = _load()
     verts = np.ascontiguousarray(verts, np.float32)
@@ -46,7 +46,8 @@ def multiview_render(verts, tris, uvs, texture, transform_stack) -> np.ndarray:
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None
     rc = lib.oracle_render(p(verts, C.c_float), p(uv, C.c_float), C.c_int(verts.shape[0]), p(tris, C.c_int32),
                            C.c_int(tris.shape[0]), p(tex, C.c_uint8), C.c_int(tex.shape[0] if use_tex else 0),
-                           C.c_int(tex.shape[1] if use_tex else 0), p(rot, C.c_double), C.c_int(n), p(out, C.c_float))
+                           C.c_int(tex.shape[1] if use_tex else 0), p(rot, C.c_double), C.c_int(n),
+                           C.c_int(1 if shading == "geometry" else 0), p(out, C.c_float))
     if rc != 0:
         raise MemoryError("oracle_render failed")
     return out

@@ -217,3 +217,21 @@ def test_collapsed_upsampled_conv_equals_conv_of_upsampled():
             y = torch.nn.functional.conv2d(xp[:, :, a:a + 7, b:b + 8], w2)
             got[:, :, a::2, b::2] = y
     assert torch.allclose(got, want, atol=1e-5)
+
+
+def test_prealign_round_trip():
+    from mvlm_amd.utils.mesh_io import Mesh
+    from mvlm_amd.utils.prealign import apply_prealign, landmarks_to_original_space, prealign_matrix
+
+    rs = np.random.RandomState(2)
+    verts = (rs.standard_normal((50, 3)) * 3 + [10, -4, 7]).astype(np.float32)
+    mesh = Mesh(verts, np.array([[0, 1, 2]], np.int32))
+    cfg = dict(align_center_of_mass=True, rot_x=-35, rot_y=10, rot_z=180, scale=20)
+    out, m = apply_prealign(mesh, cfg)
+    # centre of mass goes to the origin, distances scale by 20
+    np.testing.assert_allclose(out.verts.astype(np.float64).mean(0), 0, atol=1e-4)
+    d0 = np.linalg.norm(verts[0].astype(np.float64) - verts[1])
+    np.testing.assert_allclose(np.linalg.norm(out.verts[0].astype(np.float64) - out.verts[1]), 20 * d0, rtol=1e-5)
+    back = landmarks_to_original_space(out.verts.astype(np.float64), m)
+    np.testing.assert_allclose(back, verts, atol=1e-4)
+    assert np.array_equal(prealign_matrix(verts, dict(scale=1)), np.eye(4))
