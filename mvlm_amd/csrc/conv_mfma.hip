@@ -185,12 +185,15 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             });
             __builtin_amdgcn_sched_barrier(0);
         }
+        // two waves share a SIMD (two workgroups per CU): the one inside its MFMA run keeps the pipe
+        __builtin_amdgcn_s_setprio(1);
         static_for<0, C::MT * C::NT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int m = i / C::NT, n = i % C::NT;
             if constexpr (i >= LEAD)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
         });
+        __builtin_amdgcn_s_setprio(0);
         // keep each step's LDS prefetch and side work inside its own MFMA shadow
         __builtin_amdgcn_sched_barrier(0);
     });

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --cpu-views 0 $*"
 echo "== kernel trace" | tee -a $OUT/log.txt
