@@ -100,7 +100,7 @@ struct StageRegs {
 template <class C, int T>
 __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
                                            const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
-                                           StageRegs<C>& r) {
+                                           StageRegs<C>& r, float* st_dst) {
     if constexpr (T < C::X_ITERS) {
         const int c = cb + (tid + T * 256) / C::PLANE;
         const bool ok = goff[T] != INVALID_OFF && c < a.cin;
@@ -115,7 +115,18 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
     } else {
         constexpr int I = T - C::X_ITERS;
         const float* const base = a.w + size_t(cb) * a.cout_pad;  // wave-uniform
+#if defined(MVLM_W_DMA)
+        // weights go global -> LDS directly (LDS-DMA): one wave instruction deposits the wave's
+        // 64 float4s (1 KiB, lane-linear) into the destination stage, no VGPR round trip
+        if (woff_g[I] != INVALID_OFF) {
+            const int wave_first = (tid & ~63) + I * 256;  // first float4 slot of this wave's piece
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(base + woff_g[I]),
+                (__attribute__((address_space(3))) void*)(st_dst + C::XT_PAD + wave_first * 4), 16, 0, 0);
+        }
+#else
         r.wv[I] = *reinterpret_cast<const f32x4*>(base + (woff_g[I] != INVALID_OFF ? woff_g[I] : 0u));
+#endif
     }
 }
 
@@ -132,9 +143,11 @@ __device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, f
         v = ok ? v : 0.f;
         if (e < C::XT) st[e] = v;
     } else {
+#if !defined(MVLM_W_DMA)
         constexpr int I = T - C::X_ITERS;
         const int f = tid + I * 256;
         if (f < C::WT / 4) reinterpret_cast<f32x4*>(st + C::XT_PAD)[f] = r.wv[I];
+#endif
     }
 }
 
@@ -180,8 +193,12 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
         if constexpr (STAGE_NEXT) {
             static_for<0, T_TOT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                if constexpr ((t * HALF) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r);
+#if !defined(MVLM_ABLATE_NO_LOADS)
+                if constexpr ((t * HALF) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r, st_next);
+#endif
+#if !defined(MVLM_ABLATE_NO_WRITES)
                 if constexpr (HALF + (t * HALF) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
+#endif
             });
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     }
     StageRegs<C> regs;
     constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
-    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value>(a, 0, tid, HWin, sbn, goff, woff_g, regs); });
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value>(a, 0, tid, HWin, sbn, goff, woff_g, regs, smem); });
     static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, 0, tid, smem, goff, regs); });
     __syncthreads();
 
@@ -306,7 +323,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         compute_chunk<C, true>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
                                goff, woff_g, regs, acc);
 #endif
+#if !defined(MVLM_ABLATE_NO_BARRIER)
         __syncthreads();  // next stage complete; everybody is done reading this one
+#endif
         cur ^= 1;
     }
     compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc);
