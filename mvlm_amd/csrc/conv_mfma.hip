@@ -53,9 +53,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // COUT_T x (TW x TRI x NIMG) output tile, KS x KS taps, CK input channels per LDS stage
-template <int COUT_T_, int TW_, int TRI_, int NIMG_, int KS_, int CK_>
+// SPLITK: the four waves of a workgroup share ONE 32x32 output tile and each sums a quarter of
+// every K-chunk's channels (latency-bound tiny feature maps: 4x more workgroups, 4x shorter serial
+// K loop per wave); the partial sums are added in wave order through LDS, i.e. deterministically.
+template <int COUT_T_, int TW_, int TRI_, int NIMG_, int KS_, int CK_, bool SPLITK_ = false>
 struct Cfg {
     static constexpr int COUT_T = COUT_T_, TW = TW_, TRI = TRI_, NIMG = NIMG_, KS = KS_, CK = CK_;
+    static constexpr bool SPLITK = SPLITK_;
+    static constexpr int CKW = SPLITK ? CK / 4 : CK;  // channels of a chunk one wave multiplies
     static constexpr int TAPS = KS * KS;
     static constexpr int HALO = KS == 1 ? 0 : 1;  // KS == 2: a 2x2 window inside the 3x3 halo tile
     static constexpr int PW = TW + 2 * HALO;
@@ -67,18 +72,19 @@ struct Cfg {
     static constexpr int WT = TAPS * CK * COUT_T;
     static constexpr int STAGE = XT_PAD + WT;  // floats per LDS stage (two stages)
     static constexpr int MT = COUT_T / 32;
-    static constexpr int NT = PIX_T / 4 / 32;
-    static constexpr int KSTEPS = TAPS * CK / 2;
+    static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
+    static constexpr int KSTEPS = TAPS * CKW / 2;
     static constexpr int X_ITERS = (XT + 255) / 256;
     static constexpr int W_ITERS = (WT / 4 + 255) / 256;
     static constexpr int BN_MAXC = 256;  // pre-BN scale/shift of up to 256 input channels live in LDS
     static constexpr size_t LDS_BYTES = size_t(2 * STAGE + 2 * BN_MAXC) * 4;
     // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
     // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
-    static constexpr int ACC_REGS = (COUT_T / 32) * (TW * TRI * NIMG / 128) * 16;
+    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16;
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
-    static_assert(PIX_T % 128 == 0, "pixel tile must split into 4 waves x 32-pixel MFMA columns");
+    static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
+                  "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
     static_assert(COUT_T % 32 == 0, "cout tile must be a multiple of the 32-row MFMA tile");
     static_assert(CK % 2 == 0, "the f32 MFMA consumes two k values per step");
     static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's 160 KiB LDS");
@@ -172,7 +178,7 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
         constexpr int ks = decltype(ksc)::value;
         constexpr int nx = ks + 1;
         if constexpr (nx < C::KSTEPS) {
-            constexpr int tap = nx / (C::CK / 2), cp = nx % (C::CK / 2);
+            constexpr int tap = nx / (C::CKW / 2), cp = nx % (C::CKW / 2);
             constexpr int toff = (tap / C::KS) * C::PW + (tap % C::KS);
 #pragma unroll
             for (int m = 0; m < C::MT; ++m) av[nx & 1][m] = st[woff + (tap * C::CK + 2 * cp) * C::COUT_T + m * 32];
@@ -284,14 +290,15 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     int pixoff[C::NT];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
-        const int p = wave * (C::PIX_T / 4) + n * 32 + l31;
+        const int p = (C::SPLITK ? 0 : wave * (C::PIX_T / 4)) + n * 32 + l31;
         const int x = p % C::TW;
         const int rr = p / C::TW;
         const int yl = rr % C::TRI;
         const int img = rr / C::TRI;
-        pixoff[n] = (img * C::PH + yl) * C::PW + x + half * C::PLANE + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0);
+        pixoff[n] = (img * C::PH + yl) * C::PW + x + half * C::PLANE + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0) +
+                    (C::SPLITK ? wave * C::CKW * C::PLANE : 0);
     }
-    const int woff = C::XT_PAD + half * C::COUT_T + l31;
+    const int woff = C::XT_PAD + half * C::COUT_T + l31 + (C::SPLITK ? wave * C::CKW * C::COUT_T : 0);
 
     f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -344,6 +351,22 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         return;
     }
 #endif
+    if constexpr (C::SPLITK) {
+        // add the four waves' partial tiles in wave order (deterministic), wave 0 finishes alone
+        __syncthreads();  // every wave is done reading the stages: reuse them as the exchange buffer
+        float* red = smem;
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+    }
+
     // ---------------------------------- epilogue ---------------------------------------
     // Addresses are wave-uniform channel bases (scalar registers) + one 32-bit per-lane offset per
     // tensor and pixel column, so an element costs a load/add/store, not 64-bit vector arithmetic.
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     unsigned o_raw[C::NT], o_r1[C::NT], o_r2[C::NT], o_out[C::NT], o_skip[C::NT];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
-        const int p = wave * (C::PIX_T / 4) + n * 32 + l31;
+        const int p = (C::SPLITK ? 0 : wave * (C::PIX_T / 4)) + n * 32 + l31;
         const int rr = p / C::TW;
         const int b = b0 + rr / C::TRI;
         const int y = y0 + rr % C::TRI, x = x0 + p % C::TW;
@@ -543,7 +566,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     X(8, "conv3x3_c128_t4x32", Cfg<128, 32, 4, 1, 3, 4>)        \
     X(9, "conv3x3_c64_t4x32", Cfg<64, 32, 4, 1, 3, 4>)          \
     X(10, "conv3x3_c64_t8x32", Cfg<64, 32, 8, 1, 3, 4>)         \
-    X(11, "conv2x2_c96_t8x32", Cfg<96, 32, 8, 1, 2, 4>)
+    X(11, "conv2x2_c96_t8x32", Cfg<96, 32, 8, 1, 2, 4>)         \
+    X(12, "conv3x3_sk_t2x16", Cfg<32, 16, 2, 1, 3, 32, true>)    \
+    X(13, "conv3x3_sk_t4x8", Cfg<32, 8, 4, 1, 3, 32, true>)      \
+    X(14, "conv3x3_sk_t4x4x2", Cfg<32, 4, 4, 2, 3, 32, true>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -608,10 +634,14 @@ int pick_variant(const ConvArgs& a) {
         }
         return (a.H % 16 == 0) ? 3 : -1;
     }
-    if (a.cin_pad % 16 != 0) return -1;
-    if (a.W == 16) return 5;
-    if (a.W == 8) return 6;
-    if (a.W == 4) return 7;
+    // tiny feature maps: few pixels in total -> the split-K tiles (32 pixels per workgroup, four
+    // waves share the K loop) shorten the serial chain; larger batches keep the 128-pixel tiles
+    static const bool no_sk = getenv("MVLM_CONV_NO_SPLITK") != nullptr;
+    const long px_total = long(a.B) * a.H * a.W;
+    const bool sk = !no_sk && a.cin_pad % 32 == 0 && px_total <= 8192 && !a.amax_val;
+    if (a.W == 16) return sk ? 12 : (a.cin_pad % 16 == 0 ? 5 : -1);
+    if (a.W == 8) return sk ? 13 : (a.cin_pad % 16 == 0 ? 6 : -1);
+    if (a.W == 4) return sk ? 14 : (a.cin_pad % 16 == 0 ? 7 : -1);
     return -1;
 }
 
