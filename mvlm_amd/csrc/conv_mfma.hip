@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     X(11, "conv2x2_c96_t8x32", Cfg<96, 32, 8, 1, 2, 4>)         \
     X(12, "conv3x3_sk_t2x16", Cfg<32, 16, 2, 1, 3, 32, true>)    \
     X(13, "conv3x3_sk_t4x8", Cfg<32, 8, 4, 1, 3, 32, true>)      \
-    X(14, "conv3x3_sk_t4x4x2", Cfg<32, 4, 4, 2, 3, 32, true>)
+    X(14, "conv3x3_sk_t4x4x2", Cfg<32, 4, 4, 2, 3, 32, true>)    \
+    X(15, "conv3x3_sk_t1x32", Cfg<32, 32, 1, 1, 3, 32, true>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -620,6 +621,9 @@ int pick_variant(const ConvArgs& a) {
     }();
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
     if (a.ksize == 2) return (a.W >= 32 && a.cout_pad == 96 && a.H % 8 == 0) ? 11 : -1;
+    if (a.W == 32 && a.cin_pad % 32 == 0 && !a.amax_val && !getenv("MVLM_CONV_NO_SPLITK") &&
+        long(a.B) * a.H * a.W <= (getenv("MVLM_CONV_SPLITK_PX") ? atol(getenv("MVLM_CONV_SPLITK_PX")) : 8192))
+        return 15;  // small batch at the 32x32 level: split-K tiles, see below
     if (a.W >= 32) {
         // two workgroups fit a CU: below ~512 workgroups the 128-pixel tiles fill the chip better
         const long px = long(a.B) * a.H * a.W;
@@ -638,7 +642,8 @@ int pick_variant(const ConvArgs& a) {
     // waves share the K loop) shorten the serial chain; larger batches keep the 128-pixel tiles
     static const bool no_sk = getenv("MVLM_CONV_NO_SPLITK") != nullptr;
     const long px_total = long(a.B) * a.H * a.W;
-    const bool sk = !no_sk && a.cin_pad % 32 == 0 && px_total <= 8192 && !a.amax_val;
+    static const long sk_px = getenv("MVLM_CONV_SPLITK_PX") ? atol(getenv("MVLM_CONV_SPLITK_PX")) : 8192;
+    const bool sk = !no_sk && a.cin_pad % 32 == 0 && px_total <= sk_px && !a.amax_val;
     if (a.W == 16) return sk ? 12 : (a.cin_pad % 16 == 0 ? 5 : -1);
     if (a.W == 8) return sk ? 13 : (a.cin_pad % 16 == 0 ? 6 : -1);
     if (a.W == 4) return sk ? 14 : (a.cin_pad % 16 == 0 ? 7 : -1);
