@@ -15,6 +15,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
                 k = row.get("Kernel_Name", "?")
                 k = k.replace("(anonymous namespace)::", "").replace("void ", "")
                 k = k.split("(ConvArgs")[0].split("(rm_vert")[0].split("(float")[0].split("(double")[0][:90]
+                k = k.replace(", false>, ", ">, ")  # Cfg<..., SPLITK=false> prints like the older 6-parameter form
                 c = row.get("Counter_Name")
                 v = float(row.get("Counter_Value", 0) or 0)
                 agg[k][c] += v
