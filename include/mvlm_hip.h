@@ -46,6 +46,21 @@ int mvlm_synchronize(mvlm_ctx* ctx);
 /* name of the GPU architecture the library was built for ("gfx950") */
 const char* mvlm_build_arch(void);
 
+/* ---- OBJ ingest on the host (replaces utils3d.py:16-24, vtkOBJReader) ------------ */
+/* Parses a Wavefront OBJ into float32 points, one texture coordinate per point (a point is
+ * duplicated when it is used with several `vt` indices), polygons as triangle fans; `.mtl`,
+ * normals and groups are ignored.  Needs no ctx and no GPU.  Errors mirror the reference's
+ * ValueErrors: missing file (utils3d.py:13-14), no points (:20-21). */
+typedef struct mvlm_obj mvlm_obj;
+enum { MVLM_OBJ_ERR_ARGS = 1, MVLM_OBJ_ERR_FILE = 2, MVLM_OBJ_ERR_EMPTY = 3, MVLM_OBJ_ERR_INDEX = 4,
+       MVLM_OBJ_ERR_SYNTAX = 5 };
+int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int err_len);
+int mvlm_obj_info(const mvlm_obj* obj, int64_t* n_verts, int64_t* n_tris, int* has_uvs);
+/* copies into caller arrays sized from mvlm_obj_info: verts f32[V,3], uvs f32[V,2] (may be NULL),
+ * tris i32[T,3] */
+int mvlm_obj_copy(const mvlm_obj* obj, float* verts, float* uvs, int32_t* tris);
+void mvlm_obj_free(mvlm_obj* obj);
+
 /* ---- mesh (replaces utils3d.py:10-85 obj_to_actor's upload half) ---------------- */
 /* verts f32[V,3], uvs f32[V,2] or NULL, tris i32[T,3], tex u8[H,W,3] (row 0 = top of
  * the image file) or NULL (=> pure white mesh, utils3d.py:58-64).  Host pointers;

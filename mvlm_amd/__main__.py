@@ -52,9 +52,8 @@ def main(argv=None) -> int:
         print(f"Pipeline: {pname}")
         dm = pipeline.create_pipeline(pname, render_image_stack=args.visualize_method, n_views=args.n_views,
                                       weights=args.weights, device=args.device)
-        for file in obj_files:
+        for file, landmarks in dm.predict_files(obj_files):  # ingest of the next scan overlaps the GPU work
             print(f"Current file: {file}")
-            landmarks = dm.predict_one_file(file)
             if landmarks is None:
                 print(f"Landmarks for {file} could not be predicted -> skipping file [{file.stem}] for pipeline {pname}")
                 continue

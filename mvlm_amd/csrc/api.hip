@@ -47,6 +47,7 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
     for (auto& kv : ctx->scratch)
         if (kv.second.first) hipFree(kv.second.first);
     if (ctx->cnn.blob) hipFree(ctx->cnn.blob);
+    for (auto& e : ctx->mesh_pool) hipFree(e.first);
     if (ctx->render_overflow_host) hipHostFree(ctx->render_overflow_host);
     for (auto e : ctx->cnn.event_pool)
         if (e) hipEventDestroy(e);
@@ -81,14 +82,34 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     auto* m = new mvlm_mesh();
     m->n_verts = n_verts;
     m->n_tris = n_tris;
-    auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
-        if (hipMalloc(dst, bytes) != hipSuccess) return false;
+    // a recycled buffer may still be read by work enqueued for the mesh that owned it
+    if (!ctx->mesh_pool.empty()) MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto up = [&](void** dst, size_t* cap, const void* src, size_t bytes) -> bool {
+        int best = -1;
+        for (int i = 0; i < int(ctx->mesh_pool.size()); ++i) {
+            const size_t c = ctx->mesh_pool[i].second;
+            if (c >= bytes && c <= 4 * bytes + (1u << 20) && (best < 0 || c < ctx->mesh_pool[best].second)) best = i;
+        }
+        if (best >= 0) {
+            *dst = ctx->mesh_pool[best].first;
+            *cap = ctx->mesh_pool[best].second;
+            ctx->mesh_pool_bytes -= *cap;
+            ctx->mesh_pool.erase(ctx->mesh_pool.begin() + best);
+        } else {
+            *cap = (bytes + 65535) / 65536 * 65536;
+            if (hipMalloc(dst, *cap) != hipSuccess) {
+                *dst = nullptr;
+                *cap = 0;
+                return false;
+            }
+        }
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    bool ok = up((void**)&m->verts, verts_host, size_t(n_verts) * 12) && up((void**)&m->tris, tris_host, size_t(n_tris) * 12);
-    if (ok && uvs_host) ok = up((void**)&m->uvs, uvs_host, size_t(n_verts) * 8);
+    bool ok = up((void**)&m->verts, &m->cap[0], verts_host, size_t(n_verts) * 12) &&
+              up((void**)&m->tris, &m->cap[2], tris_host, size_t(n_tris) * 12);
+    if (ok && uvs_host) ok = up((void**)&m->uvs, &m->cap[1], uvs_host, size_t(n_verts) * 8);
     if (ok && tex_host && uvs_host) {
-        ok = up((void**)&m->tex, tex_host, size_t(tex_h) * tex_w * 3);
+        ok = up((void**)&m->tex, &m->cap[3], tex_host, size_t(tex_h) * tex_w * 3);
         m->tex_h = tex_h;
         m->tex_w = tex_w;
     }
@@ -100,13 +121,24 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     return 0;
 }
 
+// ctx == NULL (or a pool that is full): plain hipFree
 extern "C" void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* m) {
-    (void)ctx;
     if (!m) return;
-    if (m->verts) hipFree(m->verts);
-    if (m->uvs) hipFree(m->uvs);
-    if (m->tris) hipFree(m->tris);
-    if (m->tex) hipFree(m->tex);
+    void* bufs[4] = {m->verts, m->uvs, m->tris, m->tex};
+    constexpr size_t POOL_MAX_BYTES = size_t(1) << 30;
+    constexpr size_t POOL_MAX_ENTRIES = 32;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        for (int i = 0; i < 4; ++i)
+            if (bufs[i] && m->cap[i] && ctx->mesh_pool.size() < POOL_MAX_ENTRIES &&
+                ctx->mesh_pool_bytes + m->cap[i] <= POOL_MAX_BYTES) {
+                ctx->mesh_pool.emplace_back(bufs[i], m->cap[i]);
+                ctx->mesh_pool_bytes += m->cap[i];
+                bufs[i] = nullptr;
+            }
+    }
+    for (void* b : bufs)
+        if (b) hipFree(b);
     delete m;
 }
 

@@ -100,6 +100,7 @@ struct mvlm_mesh {
     int32_t* tris = nullptr;  // [T,3]
     uint8_t* tex = nullptr;   // [H,W,3] or null
     int n_verts = 0, n_tris = 0, tex_h = 0, tex_w = 0;
+    size_t cap[4] = {0, 0, 0, 0};  // allocation sizes of verts / uvs / tris / tex (for the ctx's mesh pool)
 };
 
 struct mvlm_ctx {
@@ -112,6 +113,10 @@ struct mvlm_ctx {
     std::map<std::string, std::pair<void*, size_t>> scratch;
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render
+    // device buffers of freed meshes, reused by the next upload: a folder of scans would otherwise pay
+    // four hipMalloc + four (device-synchronising) hipFree per scan
+    std::vector<std::pair<void*, size_t>> mesh_pool;
+    size_t mesh_pool_bytes = 0;
     int fail(const std::string& m) {
         err = m;
         return 1;

@@ -28,6 +28,11 @@ from ..utils.render3d import HipRenderer3D
 __all__ = ["Pipeline"]
 
 
+def _drop(box: list) -> None:
+    """Release the last reference to whatever ``box`` holds on the calling (reader) thread."""
+    box.clear()
+
+
 class TimeMixin:
     def __init__(self):
         self.start_time = time.time()
@@ -190,12 +195,58 @@ class Pipeline(abc.ABC, TimeMixin):
             float(e3.threshold_absolute), C.c_void_p(mask.data_ptr()), C.c_void_p(count.data_ptr())), ValueError)
         return count.cpu().numpy()
 
-    def _predict_fused(self, file_name: Path):
+    def predict_files(self, files, prefetch: int = 2):
+        """``predict_one_file`` over many scans, yielding ``(file, landmarks | None)`` in order.
+
+        The reference's CLI loops ``predict_one_file`` (main.py:55-62), paying file ingest and GPU
+        work back to back.  Here a reader thread parses the next ``prefetch`` OBJ/JPEG pairs
+        (native reader + libjpeg, both outside the GIL) while the GPU works on the current scan,
+        so a folder runs at the GPU rate.  Results equal the sequential loop's: poses and RANSAC
+        draws are taken on the calling thread in file order."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        from ..utils.mesh_io import load_obj
+
+        files = [Path(f) for f in files]
+        if self.predictor_2d is None:
+            raise ValueError("Predictor2D is not initialized.")
+        if not self._fusable() or prefetch <= 0:
+            for f in files:
+                yield f, self.predict_one_file(f)
+            return
+
+        def ingest(f: Path):
+            if not f.exists():
+                return None
+            return load_obj(self.renderer_3d._check_file(f))
+
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvlm-ingest") as pool:
+            pending = [pool.submit(ingest, f) for f in files[:prefetch]]
+            for i, f in enumerate(files):
+                if i + prefetch < len(files):
+                    pending.append(pool.submit(ingest, files[i + prefetch]))
+                full_s = time.time()
+                mesh = pending.pop(0).result()  # re-raises the reader's ValueError / FileNotFoundError
+                if mesh is None:
+                    print(f"File {f} does not exist")
+                    yield f, None
+                    continue
+                landmarks = self._predict_fused(f, mesh=mesh)
+                # returning a scan's 10-25 MB of host arrays to the OS costs milliseconds (page
+                # unmapping under the GPU driver's MMU notifier): let the reader thread drop them
+                # while this thread goes on to the next scan
+                pool.submit(_drop, [mesh])
+                del mesh
+                self._say("Landmarks 3D Total: ", self.p_time(time.time() - full_s))
+                yield f, landmarks
+
+    def _predict_fused(self, file_name: Path, mesh=None):
         from ..utils.mesh_io import load_obj
 
         self.tic()
-        file_name = self.renderer_3d._check_file(file_name)
-        mesh = load_obj(file_name)
+        if mesh is None:
+            file_name = self.renderer_3d._check_file(file_name)
+            mesh = load_obj(file_name)
         sharded = self.shard_views and parallel.is_distributed()
         if sharded:
             rank, _ = parallel.rank_world()

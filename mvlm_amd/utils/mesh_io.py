@@ -80,17 +80,50 @@ def _parse_obj(text: str):
     return pos, tex, out_v, out_t, tris
 
 
-def load_obj(path: Union[Path, str], load_texture: bool = True) -> Mesh:
-    path = Path(path)
-    if not path.is_file():
-        raise ValueError(f"File {path} does not exist.")  # utils3d.py:13-14
+def _read_texture(jpg: Path):
+    try:
+        from PIL import Image
+
+        with Image.open(jpg) as im:
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+    except Exception:  # noqa: BLE001 - "if we cannot load the texture, we just ignore it" (utils3d.py:35-36)
+        return None
+
+
+def _read_obj_native(path: Path):
+    """Parse with the library's reader (mvlm_obj_read, mvlm_amd/csrc/obj_reader.hip)."""
+    import ctypes as C
+
+    from .. import _lib
+
+    lib = _lib.load()
+    handle = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.mvlm_obj_read(str(path).encode(), C.byref(handle), err, len(err))
+    if rc != 0:
+        raise ValueError(err.value.decode(errors="replace") or f"File {path}: OBJ reader failed ({rc})")
+    try:
+        nv, nt, has_uv = C.c_int64(), C.c_int64(), C.c_int()
+        lib.mvlm_obj_info(handle, C.byref(nv), C.byref(nt), C.byref(has_uv))
+        verts = np.empty((nv.value, 3), np.float32)
+        tris = np.empty((nt.value, 3), np.int32)
+        uvs = np.empty((nv.value, 2), np.float32) if has_uv.value else None
+        lib.mvlm_obj_copy(handle, _lib.as_ptr(verts, C.c_float), _lib.as_ptr(uvs, C.c_float) if uvs is not None else None,
+                          _lib.as_ptr(tris, C.c_int32))
+    finally:
+        lib.mvlm_obj_free(handle)
+    return verts, tris, uvs
+
+
+def _read_obj_python(path: Path):
+    """The same rules in plain Python (the statement tests check the native reader against)."""
     pos, tex, out_v, out_t, tris = _parse_obj(path.read_text(errors="replace"))
     if len(pos) == 0:
         raise ValueError(f"File {path} does not contain any points.")  # utils3d.py:20-21
     pos_a = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
     if len(tris) == 0:
         # a point cloud: keep the points, nothing to render or to snap to
-        return Mesh(pos_a, np.zeros((0, 3), np.int32), None, None, path)
+        return pos_a, np.zeros((0, 3), np.int32), None
     v_idx = np.asarray(out_v, dtype=np.int64)
     if v_idx.min() < 0 or v_idx.max() >= len(pos):
         raise ValueError(f"File {path} references a vertex that does not exist.")
@@ -101,18 +134,35 @@ def load_obj(path: Union[Path, str], load_texture: bool = True) -> Mesh:
         tex_a = np.asarray(tex, dtype=np.float32).reshape(-1, 2)
         safe = np.clip(t_idx, 0, len(tex) - 1)
         uvs = np.where((t_idx >= 0)[:, None], tex_a[safe], np.float32(0)).astype(np.float32)
-    texture = None
-    if load_texture and uvs is not None:
-        jpg = path.with_suffix(".jpg")
-        if jpg.exists():
-            try:
-                from PIL import Image
+    return np.ascontiguousarray(verts), np.asarray(tris, dtype=np.int32).reshape(-1, 3), uvs
 
-                with Image.open(jpg) as im:
-                    texture = np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
-            except Exception:  # noqa: BLE001 - "if we cannot load the texture, we just ignore it" (:35-36)
-                texture = None
-    return Mesh(np.ascontiguousarray(verts), np.asarray(tris, dtype=np.int32).reshape(-1, 3), uvs, texture, path)
+
+def load_obj(path: Union[Path, str], load_texture: bool = True, reader: str = "native") -> Mesh:
+    """OBJ + same-stem ``.jpg`` -> Mesh.  The JPEG is decoded on a second thread while the
+    geometry is parsed (both release the GIL)."""
+    path = Path(path)
+    if not path.is_file():
+        raise ValueError(f"File {path} does not exist.")  # utils3d.py:13-14
+    jpg = path.with_suffix(".jpg")
+    tex_job = None
+    if load_texture and jpg.exists():
+        import threading
+
+        box: list = [None]
+        tex_job = threading.Thread(target=lambda: box.__setitem__(0, _read_texture(jpg)), daemon=True)
+        tex_job.start()
+    try:
+        if reader == "native":
+            verts, tris, uvs = _read_obj_native(path)
+        elif reader == "python":
+            verts, tris, uvs = _read_obj_python(path)
+        else:
+            raise ValueError(f"unknown OBJ reader: {reader}")
+    finally:
+        if tex_job is not None:
+            tex_job.join()
+    texture = box[0] if (tex_job is not None and uvs is not None) else None  # utils3d.py:26: only with tcoords
+    return Mesh(verts, tris, uvs, texture, path)
 
 
 def write_obj(path: Union[Path, str], verts: np.ndarray, tris: np.ndarray, uvs: np.ndarray | None = None,

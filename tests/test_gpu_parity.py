@@ -434,6 +434,85 @@ def test_cli_writes_landmark_files(tmp_path):
     assert main(["-p", str(tmp_path / "nope")]) == 1
 
 
+@pytest.mark.parametrize("method", ["simple", "moment"])
+def test_planted_peaks_take_the_inlier_branch(ctx, method):
+    """SURVEY.md 8(d) "planted-peak": heatmaps that are Gaussians at the projections of known
+    surface points, weak and misplaced in a third of the views.  Maxima -> rays -> quantile
+    filter -> RANSAC inlier refit -> snap must (a) equal the oracle's and (b) recover the points."""
+    from mvlm_amd.utils import HipEstimator3D, HipRenderer3D, view_rotations
+    from oracle import cnn as ocnn
+    from oracle import estimator as oest
+    from oracle import surface
+
+    n, nl = 24, 12
+    m = _mesh(80, 32, 6)
+    rs = np.random.RandomState(21)
+    pts = m.verts[rs.choice(m.n_verts, nl, replace=False)].astype(np.float64)
+    np.random.seed(2)
+    poses = HipRenderer3D(n_views=n, verbose=False).generate_3d_transformations()
+    rot = view_rotations(poses).reshape(-1, 3, 3)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    heat = np.empty((n, nl, 256, 256), np.float32)
+    for v in range(n):
+        q = pts @ rot[v].T
+        col = (q[:, 0] + 150) / 300 * 256 + 0.5          # maxima report (row - 1, col - 0.5)
+        row = 255 - (q[:, 1] + 150) / 300 * 256 + 1
+        for lm in range(nl):
+            amp = 0.6 + 0.4 * rs.rand()
+            r, c = row[lm], col[lm]
+            if rs.rand() < 0.33:                          # a wrong, weak detection: filtered by its score
+                amp, r, c = 0.2 * rs.rand(), rs.uniform(40, 215), rs.uniform(40, 215)
+            heat[v, lm] = amp * np.exp(-((yy - r) ** 2 + (xx - c) ** 2) / (2 * 3.0 ** 2)) + 1e-3 * rs.rand(256, 256)
+    hd = dev(heat)
+    lms = torch.empty((nl, n, 3), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.mvlm_heatmap_maxima(ctx.handle, C.c_void_p(hd.data_ptr()), n, nl, 256,
+                                          {"simple": 0, "moment": 1}[method], C.c_void_p(lms.data_ptr())))
+    lms = lms.cpu().numpy()
+    np.testing.assert_array_equal(lms, ocnn.maxima_from_heatmaps(heat, method))
+
+    e3 = HipEstimator3D(verbose=False)
+    s, e = e3.estimate_landmark_lines(np.zeros((n, 256, 256, 4), np.float32), lms, poses)
+    np.random.seed(9)
+    out, err = e3.estimate_landmarks_from_lines(lms, s, e)
+    snapped = e3.project_landmarks_to_surface(m, out)
+    os_, oe = oest.estimate_landmark_lines(256, lms, poses)
+    np.random.seed(9)
+    want, werr = oest.estimate_landmarks_from_lines(lms, os_, oe)
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-8)
+    assert abs(err - werr) <= 1e-9 * max(1.0, abs(werr))
+    np.testing.assert_allclose(snapped, surface.project_landmarks_to_surface(m.verts, m.tris, want), rtol=0, atol=1e-8)
+    assert err < 10.0                                     # every landmark took the inlier branch (else 1e8 / NL)
+    # integer argmax = half a pixel (0.6 model units) per view; the sub-pixel centroid does better
+    assert np.linalg.norm(snapped - pts, axis=1).max() < (0.5 if method == "simple" else 0.05)
+
+
+def test_predict_files_equals_the_sequential_loop(tmp_path):
+    """Folder mode (reader thread ahead of the GPU) returns what looping predict_one_file returns."""
+    import shutil
+
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    files = [write_face_like_obj(tmp_path / f"s{i}.obj", grid=30 + 7 * i, tex_size=64, seed=i) for i in range(3)]
+    files.insert(2, tmp_path / "missing.obj")
+    shutil.copy(files[0], tmp_path / "notex.obj")  # same geometry, no .jpg next to it -> white mesh
+    files.append(tmp_path / "notex.obj")
+    pipe = pipeline.create_pipeline("dtu3d", n_views=16, weights="synthetic:2", verbose=False)
+    np.random.seed(4)
+    want = [pipe.predict_one_file(f) for f in files]
+    np.random.seed(4)
+    got = list(pipe.predict_files(files))
+    assert [f for f, _ in got] == files
+    for (f, g), w in zip(got, want):
+        if w is None:
+            assert g is None and f.name == "missing.obj"
+        else:
+            np.testing.assert_array_equal(g, w)
+    (tmp_path / "bad.obj").write_text("# nothing\n")
+    with pytest.raises(ValueError, match="does not contain any points"):
+        list(pipe.predict_files([files[0], tmp_path / "bad.obj"]))
+
+
 def test_geometry_shading_bit_exact_and_config_driven():
     """The build-defined geometry plane: HIP == CPU restatement, and a geometry+depth config selects it."""
     from mvlm_amd import config

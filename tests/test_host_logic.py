@@ -61,6 +61,66 @@ def test_obj_ingest(tmp_path):
     assert load_obj(tmp_path / "a.obj").texture is None
 
 
+def _same_mesh(a, b):
+    np.testing.assert_array_equal(a.verts.view(np.uint32), b.verts.view(np.uint32))  # bit patterns: -0.0, nan
+    np.testing.assert_array_equal(a.tris, b.tris)
+    assert (a.uvs is None) == (b.uvs is None)
+    if a.uvs is not None:
+        np.testing.assert_array_equal(a.uvs.view(np.uint32), b.uvs.view(np.uint32))
+
+
+def test_native_obj_reader_equals_python_statement(tmp_path):
+    """mvlm_obj_read (C++, in the library) against mesh_io._parse_obj on the corner cases of the format."""
+    from mvlm_amd.utils.mesh_io import load_obj
+
+    tricky = tmp_path / "t.obj"
+    tricky.write_text(
+        "# comment\nmtllib x.mtl\nv 0 0 0\nv 1.5e0 0 0 1.0\nv  1 1 0.1234567890123456789\n\tv -1.25E-3 +2 .5\n"
+        "vt 0 0\nvt 1 0\nvt 0.5 1 0\nvn 0 0 1\ng grp\nusemtl m\ns 1\n"
+        "f 1/1 2/2 3/3 4/1\nf -1/-1 -2 -3//1\nf 1/3/1 2/2/1 3/1/1\r\nf 1 2\nf 1/9 2/2 3/3\nf 1/-9 2/2 3/3\n"
+        "v 5 5 5\nf -1 1 2\nv 1e400 -1e-400 nan\nv inf -inf -0.0\nf 6 7 1 2 3\n\n   \n#f 1 2 3\n # f 1 2 3\n")
+    a, b = load_obj(tricky, reader="native"), load_obj(tricky, reader="python")
+    _same_mesh(a, b)
+    assert a.n_tris == 10 and a.uvs is not None
+    for name, text, msg in [("idx", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n", "vertex that does not exist"),
+                            ("zero", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n", "vertex that does not exist"),
+                            ("neg", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf -4 1 2\n", "vertex that does not exist"),
+                            ("num", "v 0 a 0\n", None), ("face", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 x\n", None),
+                            ("hex", "v 0x10 0 0\n", None)]:
+        p = tmp_path / f"{name}.obj"
+        p.write_text(text)
+        for reader in ("native", "python"):
+            with pytest.raises(ValueError, match=msg):
+                load_obj(p, reader=reader)
+    cloud = tmp_path / "cloud.obj"
+    cloud.write_text("v 0 0 0\nv 1 2 3\nvt 0 0\n")
+    for reader in ("native", "python"):
+        m = load_obj(cloud, reader=reader)
+        assert m.n_tris == 0 and m.n_verts == 2 and m.uvs is None
+
+
+def test_native_obj_reader_rounds_numbers_like_python(tmp_path):
+    """Every decimal spelling must land on the same float32 as Python's float() -> np.float32."""
+    from mvlm_amd.utils.mesh_io import load_obj
+
+    rs = np.random.RandomState(5)
+    vals = np.concatenate([rs.standard_normal(3000) * 10.0 ** rs.randint(-30, 30, 3000),
+                           rs.standard_normal(3000) * 100, np.float64(rs.standard_normal(3000).astype(np.float32)),
+                           [0.0, 1e22, 1e23, 9007199254740993.0, 8.5e-46, 1.4e-45, 3.4028235e38, 3.4028236e38, 5e-324]])
+    fmts = ["%r", "%.6f", "%.17g", "%.25e", "%.3E", "%+.9f", "%.40f"]
+    lines = []
+    for i in range(0, len(vals) - 2, 3):
+        f = fmts[(i // 3) % len(fmts)]
+        tok = [repr(float(v)) if f == "%r" else f % v for v in vals[i:i + 3]]
+        lines.append("v " + " ".join(tok))
+    n = len(lines)
+    lines += [f"f {i + 1} {i + 2} {i + 3}" for i in range(n - 2)]
+    p = tmp_path / "numbers.obj"
+    p.write_text("\n".join(lines) + "\n")
+    with np.errstate(over="ignore"):
+        _same_mesh(load_obj(p, reader="native"), load_obj(p, reader="python"))
+
+
 def test_synthetic_mesh_round_trips_through_obj(tmp_path):
     from mvlm_amd.utils.mesh_io import load_obj
     from mvlm_amd.utils.synthetic import face_like_mesh, write_face_like_obj
