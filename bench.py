@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--views-per-gpu", type=int, default=64)
     ap.add_argument("--device-batch", type=int, default=128)
-    ap.add_argument("--cpu-views", type=int, default=8, help="views in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-views", type=int, default=48, help="views in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dataset", default="DTU3D")
     ap.add_argument("--image-mode", default="RGB")
     args = ap.parse_args()
