@@ -140,6 +140,14 @@ int mvlm_consensus_solve(mvlm_ctx* ctx, const double* starts_dev, const double* 
 int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* pts_dev, int n_points,
                             double* out_dev);
 
+/* ---- ray clipping / depth unprojection (replaces visualization/ray_visualizer.py:172-192) */
+/* starts_dev, ends_dev f64[R,3] (e.g. the [NL,N,3] arrays of mvlm_estimate_lines) -> new_ends_dev f64[R,3]:
+ * the first intersection of each segment with the triangle surface, or the old end when it misses;
+ * hit_dev u8[R] (may be NULL) flags the hits.  Along a view ray this is the surface point the view's
+ * depth buffer stores, evaluated at the maximum's sub-pixel position. */
+int mvlm_clip_rays_to_mesh(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* starts_dev, const double* ends_dev,
+                           int n_rays, double* new_ends_dev, uint8_t* hit_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,7 +81,114 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
     }
 }
 
+// ---- first intersection of ray segments with the surface -------------------------------------
+// The reference clips every view ray to its first hit with the mesh through a vtkOBBTree
+// (src/mvlm/visualization/ray_visualizer.py:172-192).  Along a view ray that hit is the point the
+// depth buffer of that view stores, so this is also the exact (sub-pixel) form of unprojecting a
+// heatmap maximum through the rendered depth: one 3-D surface point per (landmark, view).
+// RAYS_PER_GROUP rays share every triangle fetch; Moeller-Trumbore in float64, two-sided, segment
+// parameter t in [0,1], smallest t wins, lowest triangle id on ties.
+constexpr int RAYS_PER_GROUP = 8;
+
+__device__ inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+__global__ __launch_bounds__(256) void clip_rays_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tris,
+                                                        int n_tris, const double* __restrict__ starts,
+                                                        const double* __restrict__ ends, int n_rays,
+                                                        double* __restrict__ new_ends, uint8_t* __restrict__ hit) {
+    const int r0 = blockIdx.x * RAYS_PER_GROUP;
+    V3 o[RAYS_PER_GROUP], d[RAYS_PER_GROUP];
+    double best[RAYS_PER_GROUP];
+    int best_t[RAYS_PER_GROUP];
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_GROUP; ++r) {
+        const int ray = min(r0 + r, n_rays - 1);  // the tail group repeats its last ray
+        o[r] = {starts[ray * 3], starts[ray * 3 + 1], starts[ray * 3 + 2]};
+        const V3 e = {ends[ray * 3], ends[ray * 3 + 1], ends[ray * 3 + 2]};
+        d[r] = sub(e, o[r]);
+        best[r] = INFINITY;
+        best_t[r] = 0x7fffffff;
+    }
+    for (int t = threadIdx.x; t < n_tris; t += blockDim.x) {
+        const int ia = tris[3 * t], ib = tris[3 * t + 1], ic = tris[3 * t + 2];
+        const V3 a = {verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]};
+        const V3 b = {verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]};
+        const V3 c = {verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]};
+        const V3 e1 = sub(b, a), e2 = sub(c, a);
+#pragma unroll
+        for (int r = 0; r < RAYS_PER_GROUP; ++r) {
+            const V3 pvec = cross(d[r], e2);
+            const double det = dot(e1, pvec);
+            if (det == 0.0) continue;  // parallel to the plane or a degenerate triangle
+            const double inv = 1.0 / det;
+            const V3 tvec = sub(o[r], a);
+            const double u = dot(tvec, pvec) * inv;
+            if (!(u >= 0.0 && u <= 1.0)) continue;
+            const V3 qvec = cross(tvec, e1);
+            const double v = dot(d[r], qvec) * inv;
+            if (!(v >= 0.0 && u + v <= 1.0)) continue;
+            const double tt = dot(e2, qvec) * inv;
+            if (!(tt >= 0.0 && tt <= 1.0)) continue;
+            if (tt < best[r]) {  // ascending t per thread: first minimum keeps the lowest id
+                best[r] = tt;
+                best_t[r] = t;
+            }
+        }
+    }
+    __shared__ double s_d[RAYS_PER_GROUP][4];
+    __shared__ int s_t[RAYS_PER_GROUP][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_GROUP; ++r) {
+        double bd = best[r];
+        int bt = best_t[r];
+        for (int s = 32; s >= 1; s >>= 1) {
+            const double od = __shfl_down(bd, s);
+            const int ot = __shfl_down(bt, s);
+            if (od < bd || (od == bd && ot < bt)) {
+                bd = od;
+                bt = ot;
+            }
+        }
+        if (lane == 0) {
+            s_d[r][wave] = bd;
+            s_t[r][wave] = bt;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < RAYS_PER_GROUP && r0 + int(threadIdx.x) < n_rays) {
+        const int r = threadIdx.x, ray = r0 + r;
+        double bd = s_d[r][0];
+        int bt = s_t[r][0];
+        for (int w = 1; w < 4; ++w)
+            if (s_d[r][w] < bd || (s_d[r][w] == bd && s_t[r][w] < bt)) {
+                bd = s_d[r][w];
+                bt = s_t[r][w];
+            }
+        const bool found = bt != 0x7fffffff;
+        const V3 p0 = {starts[ray * 3], starts[ray * 3 + 1], starts[ray * 3 + 2]};
+        const V3 p1 = {ends[ray * 3], ends[ray * 3 + 1], ends[ray * 3 + 2]};
+        const V3 q = found ? madd(p0, sub(p1, p0), bd) : p1;
+        new_ends[ray * 3] = q.x;
+        new_ends[ray * 3 + 1] = q.y;
+        new_ends[ray * 3 + 2] = q.z;
+        if (hit) hit[ray] = found ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int mvlm_clip_rays_to_mesh(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* starts_dev,
+                                      const double* ends_dev, int n_rays, double* new_ends_dev, uint8_t* hit_dev) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, mesh && starts_dev && ends_dev && new_ends_dev && n_rays > 0, "clip_rays_to_mesh: bad arguments");
+    MVLM_REQUIRE(ctx, mesh->n_tris > 0, "clip_rays_to_mesh: empty mesh");
+    const int groups = (n_rays + RAYS_PER_GROUP - 1) / RAYS_PER_GROUP;
+    hipLaunchKernelGGL(clip_rays_kernel, dim3(groups), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris, mesh->n_tris,
+                       starts_dev, ends_dev, n_rays, new_ends_dev, hit_dev);
+    MVLM_CHECK_HIP(ctx, hipGetLastError());
+    return 0;
+}
 
 extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* pts_dev, int n_points,
                                        double* out_dev) {

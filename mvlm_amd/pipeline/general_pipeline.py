@@ -68,6 +68,7 @@ class Pipeline(abc.ABC, TimeMixin):
         self.verbose = verbose
         self.timings: dict[str, float] = {}
         self.last_error: float | None = None
+        self._rays = None  # (mesh, starts, ends) of the current call when visualize_rays is set
         # optional "pre-align" block of a Deep-MVLM config (mvlm_amd/utils/prealign.py); the
         # reference's live pipeline has none (it renders the mesh as-is)
         self.pre_align: dict | None = None
@@ -99,14 +100,40 @@ class Pipeline(abc.ABC, TimeMixin):
         if not file_name.exists():
             print(f"File {file_name} does not exist")
             return None
-        if self.visualize_rays:
-            print("[Pipeline] Ray visualization is not part of the MI355X hot path; skipping")
+        self._rays = None
         if self._fusable():
             landmarks = self._predict_fused(file_name)
         else:
             landmarks = self._predict_slots(file_name)
         self._say("Landmarks 3D Total: ", self.p_time(time.time() - full_s))
+        if self.visualize_rays and self._rays is not None:
+            try:
+                self.dump_rays(file_name, landmarks, landmark_indices, view_indices, clip_rays_to_mesh)
+            except Exception as e:  # noqa: BLE001 - general_pipeline.py:129-130: a failed visualisation never fails the call
+                print(f"[Pipeline] Ray visualization failed: {e}")
+        self._rays = None
         return landmarks
+
+    def dump_rays(self, file_name: Path, landmarks, landmark_indices=None, view_indices=None, clip_to_mesh: bool = True):
+        """What the reference hands to its VTK ``RayVisualizer`` (general_pipeline.py:111-128), written
+        as ``<stem>_rays.npz`` for any viewer: the selected view rays (``starts``, ``ends`` [L,V,3]),
+        clipped to their first hit with the mesh when ``clip_to_mesh`` (ray_visualizer.py:172-192,
+        here on the GPU: mvlm_clip_rays_to_mesh), ``hit`` [L,V], the indices and the landmarks."""
+        mesh, starts, ends = self._rays
+        lm_idx = list(range(starts.shape[0])) if landmark_indices is None else [int(i) % starts.shape[0] for i in landmark_indices]
+        v_idx = list(range(starts.shape[1])) if view_indices is None else [int(i) % starts.shape[1] for i in view_indices]
+        fs = np.ascontiguousarray(starts[np.ix_(lm_idx, v_idx)])
+        fe = np.ascontiguousarray(ends[np.ix_(lm_idx, v_idx)])
+        hit = np.zeros(fs.shape[:2], bool)
+        if clip_to_mesh and fs.size:
+            fe, hit = self.estimator_3d.clip_rays_to_mesh(mesh, fs, fe)
+        folder = Path(self.screenshot_folder) if self.screenshot_folder else Path.cwd() / "visualization" / "ray_screenshots"
+        folder.mkdir(parents=True, exist_ok=True)
+        out = folder / f"{Path(file_name).stem}_rays.npz"
+        np.savez(out, starts=fs, ends=fe, hit=hit, landmark_indices=np.asarray(lm_idx), view_indices=np.asarray(v_idx),
+                 landmarks=np.asarray(landmarks), clipped=bool(clip_to_mesh))
+        self._say(f"[Pipeline] rays written to {out}")
+        return out
 
     # ---- fused device-resident path ----------------------------------------------------
     def predict_mesh_device(self, mesh, transform_stack):
@@ -164,6 +191,8 @@ class Pipeline(abc.ABC, TimeMixin):
                     if k >= 3:
                         table[lm] = np.random.randint(0, int(k), size=8)  # == np.random.choice(range(k), 8)
             table.update(parallel.broadcast_array(table if rank == 0 else None))
+        if self.visualize_rays:
+            self._rays = (mesh, starts.cpu().numpy(), ends.cpu().numpy())
         out, err, _ = e3.consensus_device(maxima, starts, ends, draw_fn=draw_fn)
         error = e3.mean_error(err.cpu().numpy())
         self.timings["consensus"] = time.time() - t0
@@ -284,6 +313,8 @@ class Pipeline(abc.ABC, TimeMixin):
         self.tic()
         lines_s, lines_e = self.estimator_3d.estimate_landmark_lines(image_stack, landmark_stack, transform_stack)
         self._say("Landmarks [0] - From Heatmaps: ", self.toc_p())
+        if self.visualize_rays:
+            self._rays = (pd, np.asarray(lines_s), np.asarray(lines_e))
         self.tic()
         landmarks, error = self.estimator_3d.estimate_landmarks_from_lines(landmark_stack, lines_s, lines_e)
         self._say("Landmarks [1] - From View Lines: ", self.toc_p())

@@ -95,6 +95,36 @@ class HipEstimator3D:
                                                             int(landmarks_dev.shape[0]), C.c_void_p(out.data_ptr())))
         return out
 
+    def clip_rays_device(self, mesh: Mesh, starts_dev, ends_dev):
+        """float64 [...,3] segments on the GPU -> (ends clipped to the first surface hit, hit mask uint8 [...])."""
+        torch, dev = self._torch()
+        s, e = starts_dev.contiguous(), ends_dev.contiguous()
+        if s.dtype != torch.float64 or e.dtype != torch.float64 or s.shape != e.shape or s.shape[-1] != 3:
+            raise ValueError("clip_rays: starts and ends must be float64 arrays of the same [...,3] shape")
+        out = torch.empty_like(e)
+        hit = torch.empty(tuple(e.shape[:-1]), dtype=torch.uint8, device=dev)
+        n = int(e.numel() // 3)
+        if n:
+            handle = upload_mesh(self.ctx, mesh)
+            self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            self.ctx.check(self.ctx.lib.mvlm_clip_rays_to_mesh(
+                self.ctx.handle, handle, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                C.c_void_p(hit.data_ptr())))
+        return out, hit
+
+    def clip_rays_to_mesh(self, pd, line_starts: np.ndarray, line_ends: np.ndarray):
+        """``RayVisualizer._clip_rays_to_mesh`` (visualization/ray_visualizer.py:172-192) without VTK: every
+        ray segment ends at its first intersection with the mesh (rays that miss keep their end).  Along a
+        view ray that point is what the view's depth buffer holds, i.e. the depth-aware unprojection of the
+        heatmap maximum.  Returns (new_ends f64 like line_ends, hit bool [...])."""
+        if not isinstance(pd, Mesh):
+            raise TypeError("clip_rays_to_mesh expects the Mesh handle returned by multiview_render")
+        torch, dev = self._torch()
+        s = torch.from_numpy(np.ascontiguousarray(line_starts, dtype=np.float64)).to(dev)
+        e = torch.from_numpy(np.ascontiguousarray(line_ends, dtype=np.float64)).to(dev)
+        out, hit = self.clip_rays_device(pd, s, e)
+        return out.cpu().numpy(), hit.cpu().numpy().astype(bool)
+
     @staticmethod
     def mean_error(err_per_landmark: np.ndarray) -> float:
         """sum_error / n_landmarks with the reference's left-to-right accumulation (:180-183)."""

@@ -58,3 +58,47 @@ def project_landmarks_to_surface(verts: np.ndarray, tris: np.ndarray, landmarks:
         pts, d2 = closest_point_on_triangles(landmarks[i], a, b, c)
         out[i] = pts[int(np.argmin(d2))]
     return out
+
+
+def clip_rays_to_mesh(verts: np.ndarray, tris: np.ndarray, starts: np.ndarray, ends: np.ndarray):
+    """First intersection of each segment starts[i]->ends[i] with the triangle surface.
+
+    Stands in for ``RayVisualizer._clip_rays_to_mesh``
+    (src/mvlm/visualization/ray_visualizer.py:172-192: vtkOBBTree.IntersectWithLine, first point);
+    PARITY UNPINNED against VTK itself - the first hit of a segment with a triangle soup is unique
+    up to ties, so brute-force Moeller-Trumbore in float64 is a sound oracle.
+    starts/ends [...,3] f64 -> (new_ends [...,3] f64, hit [...] bool); misses keep their end.
+    """
+    v = verts.astype(np.float64)
+    a = v[tris[:, 0]]
+    e1, e2 = v[tris[:, 1]] - a, v[tris[:, 2]] - a
+
+    def dot(p, q):
+        return (p[..., 0] * q[..., 0] + p[..., 1] * q[..., 1]) + p[..., 2] * q[..., 2]
+
+    def cross(p, q):
+        return np.stack([p[..., 1] * q[..., 2] - p[..., 2] * q[..., 1], p[..., 2] * q[..., 0] - p[..., 0] * q[..., 2],
+                         p[..., 0] * q[..., 1] - p[..., 1] * q[..., 0]], axis=-1)
+
+    shape = starts.shape[:-1]
+    s, e = starts.reshape(-1, 3), ends.reshape(-1, 3)
+    new_ends = e.copy()
+    hit = np.zeros(len(s), bool)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for i in range(len(s)):
+            d = e[i] - s[i]
+            pvec = cross(d[None, :], e2)
+            det = dot(e1, pvec)
+            inv = 1.0 / det
+            tvec = s[i][None, :] - a
+            u = dot(tvec, pvec) * inv
+            qvec = cross(tvec, e1)
+            vv = dot(d[None, :], qvec) * inv
+            t = dot(e2, qvec) * inv
+            ok = (det != 0.0) & (u >= 0.0) & (u <= 1.0) & (vv >= 0.0) & (u + vv <= 1.0) & (t >= 0.0) & (t <= 1.0)
+            if ok.any():
+                tt = np.where(ok, t, np.inf)
+                k = int(np.argmin(tt))  # first minimum = lowest triangle id
+                new_ends[i] = s[i] + tt[k] * d
+                hit[i] = True
+    return new_ends.reshape(starts.shape), hit.reshape(shape)

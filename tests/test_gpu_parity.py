@@ -434,6 +434,63 @@ def test_cli_writes_landmark_files(tmp_path):
     assert main(["-p", str(tmp_path / "nope")]) == 1
 
 
+def test_clip_rays_matches_oracle_and_the_depth_buffer(tmp_path):
+    """mvlm_clip_rays_to_mesh: (a) equals the brute-force CPU twin, misses included; (b) a ray through a
+    pixel centre ends where that view's depth buffer says the surface is (depth-aware unprojection);
+    (c) predict_one_file(visualize_rays=True) writes the clipped rays."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils import HipEstimator3D, HipRenderer3D, view_rotations
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+    from oracle import surface
+
+    m = _mesh(70, 32, 8)
+    e3 = HipEstimator3D(verbose=False)
+    rs = np.random.RandomState(4)
+    n, nl = 12, 9
+    np.random.seed(6)
+    poses = HipRenderer3D(n_views=n, verbose=False).generate_3d_transformations()
+    lms = np.empty((nl, n, 3), np.float32)
+    lms[:, :, 0] = rs.uniform(-20, 275, (nl, n))     # some maxima fall outside the silhouette -> misses
+    lms[:, :, 1] = rs.uniform(-20, 275, (nl, n))
+    lms[:, :, 2] = rs.rand(nl, n)
+    s, e = e3.estimate_landmark_lines(np.zeros((n, 256, 256, 4), np.float32), lms, poses)
+    got, hit = e3.clip_rays_to_mesh(m, s, e)
+    want, whit = surface.clip_rays_to_mesh(m.verts, m.tris, s, e)
+    np.testing.assert_array_equal(hit, whit)
+    assert 0.2 < hit.mean() < 1.0
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(got[~hit], e[~hit])
+
+    # (b) frontal view: the depth plane of pixel (row, col) is the quantised z of the hit of the ray through
+    # that pixel's centre (maxima convention: row - 1, col - 0.5 -> centre of pixel (row, col) is (row-0.5, col))
+    r = HipRenderer3D(n_views=1, verbose=False)
+    pose = np.zeros((1, 6))
+    img = r.render_device(m, pose).cpu().numpy()[0]
+    rows, cols = np.meshgrid(np.arange(20, 236, 9), np.arange(20, 236, 9), indexing="ij")
+    px = np.stack([rows.ravel() - 0.5, cols.ravel() + 0.0, np.ones(rows.size)], axis=1).astype(np.float32)[:, None, :]
+    s1, e1 = e3.estimate_landmark_lines(np.zeros((1, 256, 256, 4), np.float32), px, pose)
+    ends, h1 = e3.clip_rays_to_mesh(m, s1, e1)
+    depth = np.rint(img[rows.ravel(), cols.ravel(), 3] * 255).astype(int)
+    zbuf = (500.0 - ends[:, 0, 2]) / 1500.0
+    expect = (256 - np.trunc(255.0 * zbuf).astype(int)) % 256
+    inside = h1[:, 0]
+    assert inside.mean() > 0.3
+    assert (np.abs(depth[inside] - expect[inside]) <= 1).mean() > 0.98   # interpolation rounding at a level boundary
+    assert (depth[~inside] == 1).all()                                      # background: far plane z = 1 -> 256 - 255
+    # (c) the pipeline's ray dump
+    obj = write_face_like_obj(tmp_path / "face.obj", grid=40, tex_size=32, seed=1)
+    pipe = pipeline.create_pipeline("dtu3d", n_views=8, weights="synthetic:3", verbose=False, visualize_rays=True,
+                                    screenshot_folder=tmp_path / "rays")
+    np.random.seed(1)
+    lm = pipe.predict_one_file(obj, landmark_indices=[0, 5, -1], view_indices=[1, 2])
+    d = np.load(tmp_path / "rays" / "face_rays.npz")
+    assert d["starts"].shape == (3, 2, 3) and d["hit"].shape == (3, 2) and bool(d["clipped"])
+    np.testing.assert_array_equal(d["landmarks"], lm)
+    np.testing.assert_array_equal(d["landmark_indices"], [0, 5, 72])
+    seg = d["ends"] - d["starts"]
+    assert (np.linalg.norm(seg, axis=2)[d["hit"]] < 1000.0 - 1e-6).all()   # clipped rays got shorter
+
+
 @pytest.mark.parametrize("method", ["simple", "moment"])
 def test_planted_peaks_take_the_inlier_branch(ctx, method):
     """SURVEY.md 8(d) "planted-peak": heatmaps that are Gaussians at the projections of known
