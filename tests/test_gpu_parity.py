@@ -434,6 +434,45 @@ def test_cli_writes_landmark_files(tmp_path):
     assert main(["-p", str(tmp_path / "nope")]) == 1
 
 
+@pytest.mark.parametrize("n", [512, 1024])
+def test_fusion_at_eight_gpu_view_counts_matches_oracle(n):
+    """Weak scaling puts 64 views per GPU on one mesh: at 8 GPUs every rank fuses 512 views per landmark
+    (1024 = the kernels' documented limit).  Rays, filter, RANSAC draw and refit against the CPU oracle."""
+    from mvlm_amd.utils import HipEstimator3D, HipRenderer3D
+    from oracle import estimator as oest
+
+    nl = 73
+    rs = np.random.RandomState(n)
+    np.random.seed(5)
+    poses = HipRenderer3D(n_views=n, verbose=False).generate_3d_transformations()
+    pts = rs.uniform(-60, 60, (nl, 3))
+    from mvlm_amd.utils import view_rotations
+
+    rot = view_rotations(poses).reshape(-1, 3, 3)
+    lms = np.empty((nl, n, 3), np.float32)
+    for v in range(n):
+        q = pts @ rot[v].T
+        lms[:, v, 1] = (q[:, 0] + 150) / 300 * 256 + rs.normal(0, 0.7, nl)
+        lms[:, v, 0] = 255 - (q[:, 1] + 150) / 300 * 256 + rs.normal(0, 0.7, nl)
+        lms[:, v, 2] = rs.rand(nl)
+    bad = rs.rand(nl, n) < 0.1                       # gross outliers among the survivors too
+    lms[bad, 0] = rs.uniform(0, 255, bad.sum())
+    e3 = HipEstimator3D(verbose=False)
+    s, e = e3.estimate_landmark_lines(np.zeros((n, 256, 256, 4), np.float32), lms, poses)
+    os_, oe = oest.estimate_landmark_lines(256, lms, poses)
+    np.testing.assert_allclose(s, os_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(e, oe, rtol=0, atol=1e-9)
+    np.random.seed(8)
+    out, err = e3.estimate_landmarks_from_lines(lms, s, e)
+    np.random.seed(8)
+    want, werr = oest.estimate_landmarks_from_lines(lms, os_, oe)
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-8)
+    assert abs(err - werr) <= 1e-9 * max(1.0, abs(werr))
+    with pytest.raises(ValueError, match="1..1024 views"):
+        big = np.zeros((2, 1025, 3), np.float32)
+        e3.estimate_landmarks_from_lines(big, np.zeros((2, 1025, 3)), np.ones((2, 1025, 3)))
+
+
 def test_clip_rays_matches_oracle_and_the_depth_buffer(tmp_path):
     """mvlm_clip_rays_to_mesh: (a) equals the brute-force CPU twin, misses included; (b) a ray through a
     pixel centre ends where that view's depth buffer says the surface is (depth-aware unprojection);
