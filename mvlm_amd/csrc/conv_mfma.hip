@@ -82,6 +82,7 @@ struct Cfg {
     // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
     static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16;
     // register budget per lane: 168 at three workgroups per CU, 256 at two
+    // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
     static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
                   "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
@@ -121,18 +122,7 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
     } else {
         constexpr int I = T - C::X_ITERS;
         const float* const base = a.w + size_t(cb) * a.cout_pad;  // wave-uniform
-#if defined(MVLM_W_DMA)
-        // weights go global -> LDS directly (LDS-DMA): one wave instruction deposits the wave's
-        // 64 float4s (1 KiB, lane-linear) into the destination stage, no VGPR round trip
-        if (woff_g[I] != INVALID_OFF) {
-            const int wave_first = (tid & ~63) + I * 256;  // first float4 slot of this wave's piece
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(base + woff_g[I]),
-                (__attribute__((address_space(3))) void*)(st_dst + C::XT_PAD + wave_first * 4), 16, 0, 0);
-        }
-#else
         r.wv[I] = *reinterpret_cast<const f32x4*>(base + (woff_g[I] != INVALID_OFF ? woff_g[I] : 0u));
-#endif
     }
 }
 
@@ -149,11 +139,9 @@ __device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, f
         v = ok ? v : 0.f;
         if (e < C::XT) st[e] = v;
     } else {
-#if !defined(MVLM_W_DMA)
         constexpr int I = T - C::X_ITERS;
         const int f = tid + I * 256;
         if (f < C::WT / 4) reinterpret_cast<f32x4*>(st + C::XT_PAD)[f] = r.wv[I];
-#endif
     }
 }
 
@@ -557,7 +545,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
 #define MVLM_CONV_VARIANTS(X)                                   \
     X(0, "conv3x3_c128_t8x32", Cfg<128, 32, 8, 1, 3, 4>)        \
     X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3, 4>)          \
-    X(2, "conv3x3_c64_t16x32", Cfg<64, 32, 16, 1, 3, 4>)        \
     X(3, "conv3x3_c32_t16x32", Cfg<32, 32, 16, 1, 3, 4>)        \
     X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 8>)        \
     X(5, "conv3x3_c32_t8x16", Cfg<32, 16, 8, 1, 3, 16>)         \

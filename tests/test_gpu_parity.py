@@ -32,7 +32,7 @@ CONV_CASES = [
     # cin, cout, size, k, batch, opts
     (256, 256, 32, 3, 2, dict(bias=True, post=True)),            # variant c128 8x32, two cout tiles
     (256, 128, 64, 3, 1, dict(pre=True, res=True)),              # c128
-    (128, 64, 32, 3, 2, dict(pre=True)),                         # c64 16x32
+    (128, 64, 32, 3, 2, dict(pre=True)),                         # c64
     (64, 32, 32, 3, 1, dict(pre=True, res=True)),                # c32 16x32
     (256, 73, 32, 3, 1, dict(bias=True)),                        # c96 (73 -> 96 padded)
     (84, 84, 64, 3, 1, dict(bias=True, up=True)),                # cin padding 84 -> 88, upsampled input
