@@ -512,24 +512,48 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int coc = co < a.cout ? co : 0;
                 const float bias = a.bias ? a.bias[coc] : 0.f;
+                // value first: max over this lane's pixels, then over the 32 lanes of the half-wave with
+                // DPP-modified v_max (row_shr 1, 2, 4, 8 leave each 16-lane row's maximum in its lane 15,
+                // row_bcast15 hands it to the next row: lanes 31 / 63 hold the half-waves' maxima)
+                float vals[C::NT];
                 float best_v = -INFINITY;
-                int best_i = 0x7fffffff;
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n) {
-                    const float v = acc[m][n][r] + bias;
-                    const bool better = lane_ok[n] && (v > best_v || (v == best_v && ppix[n] < best_i));
-                    best_v = better ? v : best_v;
-                    best_i = better ? ppix[n] : best_i;
+                    vals[n] = lane_ok[n] ? acc[m][n][r] + bias : -INFINITY;
+                    best_v = fmaxf(best_v, vals[n]);
                 }
+                auto dpp_f = [](float x, auto ctrl_c, auto rows_c) {
+                    const int xi = __float_as_int(x);
+                    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false));
+                };
+                auto dpp_i = [](int x, auto ctrl_c, auto rows_c) {
+                    return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false);
+                };
+                using SHR1 = std::integral_constant<int, 0x111>;
+                using SHR2 = std::integral_constant<int, 0x112>;
+                using SHR4 = std::integral_constant<int, 0x114>;
+                using SHR8 = std::integral_constant<int, 0x118>;
+                using BC15 = std::integral_constant<int, 0x142>;
+                using ALL = std::integral_constant<int, 0xf>;
+                using ODD = std::integral_constant<int, 0xa>;
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR1{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR2{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR4{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR8{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, BC15{}, ODD{}));
+                const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 31));
+                const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 63));
+                best_v = half ? m_hi : m_lo;
+                // then the first pixel (row-major) that attains it
+                int best_i = 0x7fffffff;
 #pragma unroll
-                for (int s = 16; s >= 1; s >>= 1) {
-                    const float ov = __shfl_xor(best_v, s);
-                    const int oi = __shfl_xor(best_i, s);
-                    const bool better = ov > best_v || (ov == best_v && oi < best_i);
-                    best_v = better ? ov : best_v;
-                    best_i = better ? oi : best_i;
-                }
-                if (l31 == 0 && co < a.cout && b0 < a.B) {
+                for (int n = 0; n < C::NT; ++n) best_i = min(best_i, vals[n] == best_v ? ppix[n] : 0x7fffffff);
+                best_i = min(best_i, dpp_i(best_i, SHR1{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, SHR2{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, SHR4{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, SHR8{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, BC15{}, ODD{}));
+                if (l31 == 31 && co < a.cout && b0 < a.B) {
                     const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
                     a.amax_val[o] = best_v;
                     a.amax_idx[o] = best_i;
