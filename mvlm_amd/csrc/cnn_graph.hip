@@ -12,7 +12,8 @@
 //                                                 block of the lower hourglass level
 //   F.interpolate before conv11                -> conv11 reads its input through >>1
 //   np.argmax per (view, landmark)             -> conv11's epilogue + a tiny reduction
-// Max-pools run as a separate memory-bound kernel (1-2 % of the time).
+//   F.max_pool2d(x, 2, 2)                       -> 2x2 max in the producer's epilogue (tiles of 32-pixel
+//                                                 rows; the 4-row tiles of small batches use the pool kernel)
 //
 // All views of a batch go through each layer together (pixels of all views form the GEMM's
 // N dimension), so even the 4x4 hourglass level fills MFMA tiles.
@@ -132,7 +133,11 @@ struct Exec {
     // hi == nullptr : returns y [cout@S]
     // hi != nullptr : writes upsample2x(y) + *hi into *hi in place ([cout@2S], the hourglass
     //                 skip tensor), returns an empty tensor
-    Tensor rb(int rb_index, const Tensor& x, Tensor* hi) {
+    // pooled != nullptr : additionally returns max_pool2d(y, 2, 2) in *pooled - fused into the three
+    //                 convs' epilogues when their kernel variants support it, else by the pool
+    //                 kernel; with keep_full == false the full-resolution y is then never written
+    //                 (it is still allocated: a resampling block keeps its 1x1 output there)
+    Tensor rb(int rb_index, const Tensor& x, Tensor* hi, Tensor* pooled = nullptr, bool keep_full = true) {
         const int base = 1 + 4 * rb_index;
         const int S = x.S;
         const int cout = d(base + 1)[2] * 2;
@@ -171,62 +176,74 @@ struct Exec {
             }
         };
         Tensor t1 = alloc(h, S), t2 = alloc(q, S);
-        {
-            ConvArgs a;
-            a.out_raw = t1.p;
-            a.raw_ctot = h;
-            common(a, 0);
-            conv(base + 1, x, a, S);
+        ConvArgs a1, a2, a3;
+        a1.out_raw = t1.p;
+        a1.raw_ctot = h;
+        common(a1, 0);
+        a2.out_raw = t2.p;
+        a2.raw_ctot = q;
+        common(a2, h);
+        common(a3, h + q);
+        bool fused_pool = false;
+        if (pooled && !hi) {
+            *pooled = alloc(cout, S / 2);
+            fused_pool = pool_fusable(base + 1, x, a1, S) && pool_fusable(base + 2, t1, a2, S) && pool_fusable(base + 3, t2, a3, S);
+            if (fused_pool) {
+                for (ConvArgs* a : {&a1, &a2, &a3}) {
+                    a->pool_out = pooled->p;
+                    a->pool_ctot = cout;
+                    a->pool_coff = a->out_coff;
+                    if (!keep_full) a->out = nullptr;
+                }
+            }
         }
-        {
-            ConvArgs a;
-            a.out_raw = t2.p;
-            a.raw_ctot = q;
-            common(a, h);
-            conv(base + 2, t1, a, S);
-        }
-        {
-            ConvArgs a;
-            common(a, h + q);
-            conv(base + 3, t2, a, S);
-        }
+        conv(base + 1, x, a1, S);
+        conv(base + 2, t1, a2, S);
+        conv(base + 3, t2, a3, S);
         release(t1);
         release(t2);
+        if (pooled && !hi && !fused_pool && !dry && !rc && mvlm_launch_maxpool2(ctx, y.p, B * cout, S, S, pooled->p)) rc = 1;
         return y;
     }
 
-    Tensor pool(const Tensor& x) {
-        Tensor o = alloc(x.C, x.S / 2);
-        if (!dry && !rc && mvlm_launch_maxpool2(ctx, x.p, B * x.C, x.S, x.S, o.p)) rc = 1;
-        return o;
+    // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
+    bool pool_fusable(int slot, const Tensor& x, ConvArgs a, int S) {
+        static const bool off = getenv("MVLM_CNN_NO_POOL_FUSION") != nullptr;
+        if (off) return false;
+        const int32_t* r = d(slot);
+        a.cin = r[1];
+        a.cout = r[2];
+        a.ksize = r[3];
+        a.cin_pad = r[4];
+        a.cout_pad = r[5];
+        a.B = B;
+        a.H = a.W = S;
+        (void)x;
+        return mvlm_conv_can_pool(a);
     }
 
     // HourGlassModule.forward (paulsenpredictor.py:301-361).  rb0 = index of this
     // hourglass's rb1 in the canonical residual-block order.  Consumes nothing; the caller
     // releases x.
-    Tensor hourglass(int rb0, const Tensor& x) {
+    // x_pooled = max_pool2d(x) (the producer of x emits it from its epilogue where it can).
+    Tensor hourglass(int rb0, const Tensor& x, const Tensor& x_pooled) {
         auto R = [&](int i) { return rb0 + i - 1; };
         Tensor up1 = rb(R(1), x, nullptr);
-        Tensor lowt1 = pool(x);
-        Tensor low1 = rb(R(2), lowt1, nullptr);
-        release(lowt1);
+        Tensor lowt11, lowt12, lowt13, lowt14;
+        Tensor low1 = rb(R(2), x_pooled, nullptr, &lowt11);
         Tensor up11 = rb(R(3), low1, nullptr);
-        Tensor lowt11 = pool(low1);
         release(low1);
-        Tensor low11 = rb(R(4), lowt11, nullptr);
+        Tensor low11 = rb(R(4), lowt11, nullptr, &lowt12);
         release(lowt11);
         Tensor up12 = rb(R(5), low11, nullptr);
-        Tensor lowt12 = pool(low11);
         release(low11);
-        Tensor low12 = rb(R(6), lowt12, nullptr);
+        Tensor low12 = rb(R(6), lowt12, nullptr, &lowt13);
         release(lowt12);
         Tensor up13 = rb(R(7), low12, nullptr);
-        Tensor lowt13 = pool(low12);
         release(low12);
-        Tensor low13 = rb(R(8), lowt13, nullptr);
+        Tensor low13 = rb(R(8), lowt13, nullptr, &lowt14);
         release(lowt13);
         Tensor up14 = rb(R(9), low13, nullptr);
-        Tensor lowt14 = pool(low13);
         release(low13);
         Tensor low14 = rb(R(10), lowt14, nullptr);
         release(lowt14);
@@ -267,15 +284,17 @@ struct Exec {
             conv(0, x0, a, 256);  // conv1 + bn1 + relu
         }
         release(x0);
-        Tensor a1 = rb(0, a0, nullptr);  // conv2
+        Tensor p1;
+        Tensor a1 = rb(0, a0, nullptr, &p1, /*keep_full=*/false);  // conv2 + max-pool; only the pooled tensor is consumed
         release(a0);
-        Tensor p1 = pool(a1);
         release(a1);
         Tensor a2 = rb(1, p1, nullptr);  // conv3
         release(p1);
-        Tensor r3 = rb(2, a2, nullptr);  // conv4
+        Tensor r3p;
+        Tensor r3 = rb(2, a2, nullptr, &r3p);  // conv4 (+ its pooled copy for the hourglass)
         release(a2);
-        Tensor h1 = hourglass(3, r3);
+        Tensor h1 = hourglass(3, r3, r3p);
+        release(r3p);
         Tensor ll1 = alloc(256, 128);
         {
             ConvArgs a;
@@ -291,7 +310,7 @@ struct Exec {
             a.out_ctot = NL;
             conv(SLOT_CONV5 + 1, ll1, a, 128);  // conv6
         }
-        Tensor sum = alloc(256, 128);
+        Tensor sum = alloc(256, 128), sump;
         {
             ConvArgs a;  // conv7; sum_temp = (r3 + ll1) + x  (:422)
             a.res1 = r3.p;
@@ -300,12 +319,20 @@ struct Exec {
             a.res2_ctot = 256;
             a.out = sum.p;
             a.out_ctot = 256;
+            sump = alloc(256, 64);
+            const bool fused = pool_fusable(SLOT_CONV5 + 2, x6, a, 128);
+            if (fused) {
+                a.pool_out = sump.p;
+                a.pool_ctot = 256;
+            }
             conv(SLOT_CONV5 + 2, x6, a, 128);
+            if (!fused && !dry && !rc && mvlm_launch_maxpool2(ctx, sum.p, B * 256, 128, 128, sump.p)) rc = 1;
         }
         release(x6);
         release(r3);
         release(ll1);
-        Tensor h2 = hourglass(23, sum);
+        Tensor h2 = hourglass(23, sum, sump);
+        release(sump);
         release(sum);
         Tensor x9 = alloc(256, 128);
         {

@@ -75,6 +75,10 @@ struct ConvArgs {
     int* amax_idx = nullptr;
     int amax_parts = 0;   // partials per (image, channel) in the buffers
     int amax_part0 = 0;   // first partial this launch writes (parity launches share one buffer)
+    // fused 2x2 max-pool of the final values (F.max_pool2d(x, 2, 2), paulsenpredictor.py:304, :413):
+    // pool_out is [B][pool_ctot][H/2][W/2]; `out` may be null when only the pooled tensor is consumed
+    float* pool_out = nullptr;
+    int pool_ctot = 0, pool_coff = 0;
 };
 
 struct ConvProfileRec {
@@ -126,6 +130,7 @@ struct mvlm_ctx {
 
 // conv_mfma.hip
 int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
+bool mvlm_conv_can_pool(const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
 int mvlm_conv_amax_parts(int H, int W);  // partials per (image, channel) the argmax epilogue writes
 const char* mvlm_conv_variant_name_impl(int v);
 

@@ -362,6 +362,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     bool lane_ok[C::NT];
     int ppix[C::NT];
     unsigned o_raw[C::NT], o_r1[C::NT], o_r2[C::NT], o_out[C::NT], o_skip[C::NT];
+    // fused 2x2 max-pool: the rows of a pair are two pixel registers of one lane (n, n+1), the columns two
+    // neighbouring lanes, so it needs 32-pixel tile rows, one image per tile and an even row count per wave
+    constexpr bool CAN_POOL = !C::SPLITK && C::TW == 32 && C::NIMG == 1 && C::NT % 2 == 0;
+    unsigned o_pool[C::NT / 2 > 0 ? C::NT / 2 : 1];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int p = (C::SPLITK ? 0 : wave * (C::PIX_T / 4)) + n * 32 + l31;
@@ -376,6 +380,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         o_raw[n] = (bb * a.raw_ctot + a.raw_coff + h4) * HW + pix;
         o_r1[n] = (bb * a.res1_ctot + a.res1_coff + h4) * HW + pix;
         o_r2[n] = (bb * a.res2_ctot + a.res2_coff + h4) * HW + pix;
+        if constexpr (CAN_POOL)
+            if ((n & 1) == 0) o_pool[n / 2] = (bb * a.pool_ctot + a.pool_coff + h4) * (HW / 4) + unsigned((y >> 1) * (W >> 1) + (x >> 1));
         if (!a.up_out) {
             o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * HW + pix;
             o_skip[n] = 0;
@@ -460,6 +466,21 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             if (a.res1) {
 #pragma unroll
                 for (int e = 0; e < GE; ++e) vals[e] += resv[g & 1][e];
+            }
+            if constexpr (CAN_POOL) {
+                if (a.pool_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* const p = a.pool_out + size_t(cs0 + j) * (HW / 4);
+#pragma unroll
+                        for (int q = 0; q < C::NT / 2; ++q) {
+                            const float v2 = fmaxf(vals[j * C::NT + 2 * q], vals[j * C::NT + 2 * q + 1]);
+                            const int vi = __float_as_int(v2);
+                            const float other = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xf, 0xf, false));  // lane ^ 1
+                            if (okc[j] && (l31 & 1) == 0) p[o_pool[q]] = fmaxf(v2, other);
+                        }
+                    }
+                }
             }
             if (a.out) {
                 if (a.up_out != 1) {
@@ -674,6 +695,20 @@ const char* mvlm_conv_variant_name_impl(int v) {
     return "?";
 }
 
+bool mvlm_conv_can_pool(const ConvArgs& a) {
+    if (a.up_out || a.amax_val || (a.H & 1) || (a.W & 1)) return false;
+    switch (pick_variant(a)) {
+#define X(id, name, ...)                                                                                   \
+    case id: {                                                                                             \
+        using V = __VA_ARGS__;                                                                             \
+        return !V::SPLITK && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0;                                \
+    }
+        MVLM_CONV_VARIANTS(X)
+#undef X
+    }
+    return false;
+}
+
 int mvlm_conv_amax_parts(int H, int W) {
     // fused argmax is only used with variants 0/1 (8x32 tiles, 4 waves)
     return (W / 32) * (H / 8) * 4;
@@ -694,6 +729,9 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     MVLM_REQUIRE(ctx, a.up_out != 1 || px * a.skip_ctot * 4 < lim, "conv: skip tensor exceeds 32-bit element offsets");
     const int v = pick_variant(a);
     MVLM_REQUIRE(ctx, v >= 0, "conv: no kernel variant for this shape");
+    MVLM_REQUIRE(ctx, !a.pool_out || mvlm_conv_can_pool(a), "conv: this shape's kernel variant cannot emit the pooled tensor");
+    MVLM_REQUIRE(ctx, !a.pool_out || px / 4 * a.pool_ctot < lim, "conv: pooled output exceeds 32-bit element offsets");
+    MVLM_REQUIRE(ctx, a.out || a.pool_out || a.amax_val, "conv: no output requested");
     if (variant_out) *variant_out = v;
     switch (v) {
 #define X(id, name, ...) \
