@@ -152,7 +152,12 @@ extern "C" int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin
     MVLM_REQUIRE(ctx, ksize == 1 || ksize == 3, "conv2d: kernel size must be 1 or 3");
     MVLM_REQUIRE(ctx, (pre_scale_host == nullptr) == (pre_shift_host == nullptr), "conv2d: pre scale/shift come in pairs");
     MVLM_REQUIRE(ctx, (post_scale_host == nullptr) == (post_shift_host == nullptr), "conv2d: post scale/shift come in pairs");
-    const int cin_pad = (ksize == 1 ? (cin + 7) / 8 * 8 : (cin + 3) / 4 * 4), cout_pad = (cout + 31) / 32 * 32, taps = ksize * ksize;
+    // same padding rules as mvlm_amd/weights.py: a plain conv + bias layer on the 32-pixel-row tiles may
+    // end in one 16-row strip
+    const bool tail16 = ksize == 3 && (cout + 15) / 16 * 16 == 80 && !pre_scale_host && !post_scale_host && !r_dev &&
+                        w >= 32 && h % 8 == 0;
+    const int cin_pad = (ksize == 1 ? (cin + 7) / 8 * 8 : (cin + 3) / 4 * 4), taps = ksize * ksize;
+    const int cout_pad = tail16 ? (cout + 15) / 16 * 16 : (cout + 31) / 32 * 32;
     std::vector<float> blob;
     auto push = [&](size_t n) {
         const size_t off = blob.size();

@@ -71,8 +71,12 @@ struct Cfg {
     static constexpr int XT_PAD = (XT + 3) / 4 * 4;
     static constexpr int WT = TAPS * CK * COUT_T;
     static constexpr int STAGE = XT_PAD + WT;  // floats per LDS stage (two stages)
-    static constexpr int MT = COUT_T / 32;
+    static constexpr int MT = COUT_T / 32;  // full 32-row MFMA tiles
+    // COUT_T = 32*MT + 16: the last 16 output channels run on v_mfma_f32_16x16x4_f32 (same FLOP rate,
+    // half the rows), so a 73-landmark layer pads to 80 rows instead of 96
+    static constexpr bool TAIL16 = COUT_T % 32 == 16;
     static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
+    static constexpr int NT16 = TAIL16 ? 2 * NT : 1;  // 16-pixel column groups of a wave
     static constexpr int KSTEPS = TAPS * CKW / 2;
     static constexpr int X_ITERS = (XT + 255) / 256;
     static constexpr int W_ITERS = (WT / 4 + 255) / 256;
@@ -80,13 +84,14 @@ struct Cfg {
     static constexpr size_t LDS_BYTES = size_t(2 * STAGE + 2 * BN_MAXC) * 4;
     // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
     // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
-    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16;
+    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0);
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
     static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
                   "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
-    static_assert(COUT_T % 32 == 0, "cout tile must be a multiple of the 32-row MFMA tile");
+    static_assert(COUT_T % 32 == 0 || (TAIL16 && !SPLITK && CK == 4 && TW == 32 && NIMG == 1),
+                  "cout tile must be a multiple of the 32-row MFMA tile (+ one 16-row strip on the 32-pixel-row tiles)");
     static_assert(CK % 2 == 0, "the f32 MFMA consumes two k values per step");
     static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's 160 KiB LDS");
 };
@@ -154,10 +159,12 @@ template <class C, bool STAGE_NEXT>
 __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st, float* st_next, int cb_next, int tid,
                                               unsigned HWin, const float* sbn, int woff, const int (&pixoff)[C::NT],
                                               const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
-                                              StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT]) {
+                                              StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT], int woff16,
+                                              const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16]) {
     constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
     constexpr int HALF = C::KSTEPS / 2;
     float av[2][C::MT], bv[2][C::NT];
+    float a16 = 0.f, b16[C::NT16];  // 16-row strip: operands of one tap's four channels (two k-steps)
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) av[0][m] = st[woff + m * 32];
 #pragma unroll
@@ -172,6 +179,15 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             for (int m = 0; m < C::MT; ++m) av[nx & 1][m] = st[woff + (tap * C::CK + 2 * cp) * C::COUT_T + m * 32];
 #pragma unroll
             for (int n = 0; n < C::NT; ++n) bv[nx & 1][n] = st[2 * cp * C::PLANE + pixoff[n] + toff];
+        }
+        if constexpr (C::TAIL16 && (ks & 1) == 0) {
+            // the strip's A (16 channels x 4 k) and B (4 k x 16 pixels) fragments of this tap, used
+            // by the 16x16x4 MFMAs of the tap's second k-step
+            constexpr int tap16 = ks / 2;
+            constexpr int toff16 = (tap16 / C::KS) * C::PW + (tap16 % C::KS);
+            a16 = st[woff16 + tap16 * C::CK * C::COUT_T];
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j) b16[j] = st[pixoff16[j] + toff16];
         }
         // two MFMAs first, then this step's share of the staging work, then the rest: the side
         // work's LDS / VMEM operations complete in the shadow of the remaining MFMAs instead of
@@ -204,6 +220,10 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             if constexpr (i >= LEAD)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
         });
+        if constexpr (C::TAIL16 && (ks & 1) == 1) {
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j) acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16[j], acc16[j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         // keep each step's LDS prefetch and side work inside its own MFMA shadow
         __builtin_amdgcn_sched_barrier(0);
@@ -293,6 +313,18 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     for (int m = 0; m < C::MT; ++m)
 #pragma unroll
         for (int n = 0; n < C::NT; ++n) acc[m][n] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // 16-row strip (TAIL16): lane l multiplies channel 32*MT + (l & 15) with k = l >> 4 of a tap's four
+    // channels; result register i of column group j is channel 32*MT + 4*(l >> 4) + i at pixel 16*j + (l & 15)
+    const int q16 = lane >> 4, i16 = lane & 15;
+    const int woff16 = C::XT_PAD + q16 * C::COUT_T + C::MT * 32 + i16;
+    int pixoff16[C::NT16];
+    f32x4 acc16[C::NT16];
+#pragma unroll
+    for (int j = 0; j < C::NT16; ++j) {
+        const int p = wave * (C::PIX_T / 4) + j * 16 + i16;
+        pixoff16[j] = (p / C::TW % C::TRI) * C::PW + p % C::TW + q16 * C::PLANE + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0);
+        acc16[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // the consumer-side BatchNorm (scale, shift per input channel) is read from LDS
     float* sbn = smem + 2 * C::STAGE;
@@ -313,17 +345,17 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
 #if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
         compute_chunk<C, false>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
-                                goff, woff_g, regs, acc);
+                                goff, woff_g, regs, acc, woff16, pixoff16, acc16);
 #else
         compute_chunk<C, true>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
-                               goff, woff_g, regs, acc);
+                               goff, woff_g, regs, acc, woff16, pixoff16, acc16);
 #endif
 #if !defined(MVLM_ABLATE_NO_BARRIER)
         __syncthreads();  // next stage complete; everybody is done reading this one
 #endif
         cur ^= 1;
     }
-    compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc);
+    compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16);
 
 #if defined(MVLM_ABLATE_NO_EPILOGUE)  // timing experiment only: wrong results
     {
@@ -523,6 +555,34 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     else
         epilogue(std::false_type{});
 
+    // ---- the 16-row strip: plain conv + bias layers only (conv6, conv10, conv11; checked on the host) ----
+    int pix16[C::NT16];            // output pixel index of column group j (full resolution for up_out == 2)
+    float val16[C::NT16][4];       // acc + bias, kept for the fused argmax
+    bool ok16[4];
+    if constexpr (C::TAIL16) {
+        const unsigned b = unsigned(b0);
+#pragma unroll
+        for (int j = 0; j < C::NT16; ++j) {
+            const int p = wave * (C::PIX_T / 4) + j * 16 + i16;
+            const int y = y0 + p / C::TW, x = x0 + p % C::TW;
+            pix16[j] = a.up_out == 2 ? (2 * y + a.sub_y) * (2 * W) + 2 * x + a.sub_x : y * W + x;
+        }
+        const unsigned plane = a.up_out == 2 ? 4u * HW : HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + C::MT * 32 + 4 * q16 + i;
+            ok16[i] = co < a.cout;
+            const int coc = ok16[i] ? co : 0;
+            const float bias = a.bias ? a.bias[coc] : 0.f;
+            float* const po = a.out ? a.out + (size_t(b) * a.out_ctot + a.out_coff + coc) * plane : nullptr;
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j) {
+                val16[j][i] = acc16[j][i] + bias;
+                if (po && ok16[i]) po[pix16[j]] = val16[j][i];
+            }
+        }
+    }
+
     if constexpr (AMAX) {
         // Fused heatmap argmax (paulsenpredictor.py:123): conv11 has no residual / post-BN, so
         // the heatmap value is acc + bias.  First maximum in row-major order wins ties.
@@ -581,6 +641,45 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 }
             }
         });
+        if constexpr (C::TAIL16) {
+            // strip: a 16-lane row holds 16 pixels of channels 4*q16 + i; rows reduce on their own
+            using SHR1 = std::integral_constant<int, 0x111>;
+            using SHR2 = std::integral_constant<int, 0x112>;
+            using SHR4 = std::integral_constant<int, 0x114>;
+            using SHR8 = std::integral_constant<int, 0x118>;
+            auto dpp_f = [](float x, auto ctrl_c) {
+                const int xi = __float_as_int(x);
+                return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl_c)::value, 0xf, 0xf, false));
+            };
+            auto dpp_i = [](int x, auto ctrl_c) { return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, 0xf, 0xf, false); };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float best_v = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < C::NT16; ++j) best_v = fmaxf(best_v, val16[j][i]);
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR1{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR2{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR4{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR8{}));  // lane 15 of every row: the row's maximum
+                const int bi = __float_as_int(best_v);
+                const int r0 = __builtin_amdgcn_readlane(bi, 15), r1 = __builtin_amdgcn_readlane(bi, 31);
+                const int r2 = __builtin_amdgcn_readlane(bi, 47), r3 = __builtin_amdgcn_readlane(bi, 63);
+                best_v = __int_as_float(q16 == 0 ? r0 : q16 == 1 ? r1 : q16 == 2 ? r2 : r3);
+                int best_i = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < C::NT16; ++j) best_i = min(best_i, val16[j][i] == best_v ? pix16[j] : 0x7fffffff);
+                best_i = min(best_i, dpp_i(best_i, SHR1{}));
+                best_i = min(best_i, dpp_i(best_i, SHR2{}));
+                best_i = min(best_i, dpp_i(best_i, SHR4{}));
+                best_i = min(best_i, dpp_i(best_i, SHR8{}));
+                const int co = co0 + C::MT * 32 + 4 * q16 + i;
+                if (i16 == 15 && co < a.cout && b0 < a.B) {
+                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
+                    a.amax_val[o] = best_v;
+                    a.amax_idx[o] = best_i;
+                }
+            }
+        }
     }
 }
 
@@ -602,7 +701,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     X(12, "conv3x3_sk_t2x16", Cfg<32, 16, 2, 1, 3, 32, true>)    \
     X(13, "conv3x3_sk_t4x8", Cfg<32, 8, 4, 1, 3, 32, true>)      \
     X(14, "conv3x3_sk_t4x4x2", Cfg<32, 4, 4, 2, 3, 32, true>)    \
-    X(15, "conv3x3_sk_t1x32", Cfg<32, 32, 1, 1, 3, 32, true>)
+    X(15, "conv3x3_sk_t1x32", Cfg<32, 32, 1, 1, 3, 32, true>)    \
+    X(16, "conv3x3_c80_t8x32", Cfg<80, 32, 8, 1, 3, 4>)         \
+    X(17, "conv2x2_c80_t8x32", Cfg<80, 32, 8, 1, 2, 4>)
 
 template <class C>
 int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
@@ -613,6 +714,9 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
     MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
     MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
     MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
+    if (C::TAIL16)
+        MVLM_REQUIRE(ctx, !a.res1 && !a.res2 && !a.out_raw && !a.post_scale && a.up_out != 1 && !a.pool_out,
+                     "conv: the 80-channel tiles serve plain conv + bias layers only");
     if (a.amax_val) {
         MVLM_REQUIRE(ctx, C::NIMG == 1, "conv: fused argmax needs one image per tile");
         MVLM_REQUIRE(ctx, a.amax_part0 >= 0 && a.amax_part0 + tiles_x * tiles_y * 4 <= a.amax_parts,
@@ -652,7 +756,8 @@ int pick_variant(const ConvArgs& a) {
         return e && std::string(e) == "small";
     }();
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
-    if (a.ksize == 2) return (a.W >= 32 && a.cout_pad == 96 && a.H % 8 == 0) ? 11 : -1;
+    if (a.ksize == 2) return (a.W >= 32 && a.H % 8 == 0) ? (a.cout_pad == 96 ? 11 : a.cout_pad == 80 ? 17 : -1) : -1;
+    if (a.cout_pad == 80) return (a.W >= 32 && a.H % 8 == 0) ? 16 : -1;  // 64 rows + one 16-row strip
     if (a.W == 32 && a.cin_pad % 32 == 0 && !a.amax_val && !getenv("MVLM_CONV_NO_SPLITK") &&
         long(a.B) * a.H * a.W <= (getenv("MVLM_CONV_SPLITK_PX") ? atol(getenv("MVLM_CONV_SPLITK_PX")) : 8192))
         return 15;  // small batch at the 32x32 level: split-K tiles, see below
@@ -701,7 +806,7 @@ bool mvlm_conv_can_pool(const ConvArgs& a) {
 #define X(id, name, ...)                                                                                   \
     case id: {                                                                                             \
         using V = __VA_ARGS__;                                                                             \
-        return !V::SPLITK && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0;                                \
+        return !V::SPLITK && !V::TAIL16 && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0;                  \
     }
         MVLM_CONV_VARIANTS(X)
 #undef X
@@ -710,7 +815,7 @@ bool mvlm_conv_can_pool(const ConvArgs& a) {
 }
 
 int mvlm_conv_amax_parts(int H, int W) {
-    // fused argmax is only used with variants 0/1 (8x32 tiles, 4 waves)
+    // fused argmax is only built for the 8x32-pixel tiles (4 waves x one partial each)
     return (W / 32) * (H / 8) * 4;
 }
 

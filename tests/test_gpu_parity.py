@@ -34,7 +34,8 @@ CONV_CASES = [
     (256, 128, 64, 3, 1, dict(pre=True, res=True)),              # c128
     (128, 64, 32, 3, 2, dict(pre=True)),                         # c64
     (64, 32, 32, 3, 1, dict(pre=True, res=True)),                # c32 16x32
-    (256, 73, 32, 3, 1, dict(bias=True)),                        # c96 (73 -> 96 padded)
+    (256, 73, 32, 3, 1, dict(bias=True)),                        # c80: 73 -> 64 + one 16-row strip
+    (73, 73, 64, 3, 2, dict(bias=True, up=True)),                # c80, cin 73 -> 76, upsampled input (conv11 shape)
     (84, 84, 64, 3, 1, dict(bias=True, up=True)),                # cin padding 84 -> 88, upsampled input
     (73, 256, 32, 3, 1, dict(bias=True, res=True)),              # cin 73 -> 80
     (3, 64, 64, 3, 1, dict(bias=True, post=True)),               # conv1-like

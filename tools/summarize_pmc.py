@@ -46,7 +46,8 @@ for k in names[:24]:
 import json
 import re
 VARIANT = {"128, 32, 8, 1, 3, 4": "conv3x3_c128_t8x32", "96, 32, 8, 1, 3, 4": "conv3x3_c96_t8x32",
-           "64, 32, 16, 1, 3, 4": "conv3x3_c64_t16x32", "32, 32, 16, 1, 3, 4": "conv3x3_c32_t16x32",
+           "80, 32, 8, 1, 3, 4": "conv3x3_c80_t8x32", "80, 32, 8, 1, 2, 4": "conv2x2_c80_t8x32",
+           "32, 32, 16, 1, 3, 4": "conv3x3_c32_t16x32",
            "128, 32, 8, 1, 1, 8": "conv1x1_c128_t8x32", "32, 16, 8, 1, 3, 16": "conv3x3_c32_t8x16",
            "32, 8, 8, 2, 3, 16": "conv3x3_c32_t8x8x2", "32, 4, 4, 8, 3, 16": "conv3x3_c32_t4x4x8",
            "128, 32, 4, 1, 3, 4": "conv3x3_c128_t4x32", "64, 32, 4, 1, 3, 4": "conv3x3_c64_t4x32",
