@@ -1,0 +1,708 @@
+// Kernel template of the implicit-GEMM convolution (see conv_mfma.hip for the overview); included by
+// the translation units that instantiate groups of variants (conv_inst_g*.hip).
+#ifndef MVLM_CONV_KERNEL_H
+#define MVLM_CONV_KERNEL_H
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+
+#include "common.h"
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+constexpr unsigned INVALID_OFF = 0xFFFFFFFFu;
+
+// compile-time loop: the body sees its index as a constant, so register arrays indexed by it
+// can never be demoted to scratch by an unrolling heuristic
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// COUT_T x (TW x TRI x NIMG) output tile, KS x KS taps, CK input channels per LDS stage
+// SPLITK: the four waves of a workgroup share ONE 32x32 output tile and each sums a quarter of
+// every K-chunk's channels (latency-bound tiny feature maps: 4x more workgroups, 4x shorter serial
+// K loop per wave); the partial sums are added in wave order through LDS, i.e. deterministically.
+template <int COUT_T_, int TW_, int TRI_, int NIMG_, int KS_, int CK_, bool SPLITK_ = false>
+struct Cfg {
+    static constexpr int COUT_T = COUT_T_, TW = TW_, TRI = TRI_, NIMG = NIMG_, KS = KS_, CK = CK_;
+    static constexpr bool SPLITK = SPLITK_;
+    static constexpr int CKW = SPLITK ? CK / 4 : CK;  // channels of a chunk one wave multiplies
+    static constexpr int TAPS = KS * KS;
+    static constexpr int HALO = KS == 1 ? 0 : 1;  // KS == 2: a 2x2 window inside the 3x3 halo tile
+    static constexpr int PW = TW + 2 * HALO;
+    static constexpr int PH = TRI + 2 * HALO;
+    static constexpr int PLANE = NIMG * PH * PW;  // floats per channel in sX
+    static constexpr int PIX_T = TW * TRI * NIMG;
+    static constexpr int XT = CK * PLANE;
+    static constexpr int XT_PAD = (XT + 3) / 4 * 4;
+    static constexpr int WT = TAPS * CK * COUT_T;
+    static constexpr int STAGE = XT_PAD + WT;  // floats per LDS stage (two stages)
+    static constexpr int MT = COUT_T / 32;  // full 32-row MFMA tiles
+    // COUT_T = 32*MT + 16: the last 16 output channels run on v_mfma_f32_16x16x4_f32 (same FLOP rate,
+    // half the rows), so a 73-landmark layer pads to 80 rows instead of 96
+    static constexpr bool TAIL16 = COUT_T % 32 == 16;
+    static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
+    static constexpr int NT16 = TAIL16 ? 2 * NT : 1;  // 16-pixel column groups of a wave
+    static constexpr int KSTEPS = TAPS * CKW / 2;
+    static constexpr int X_ITERS = (XT + 255) / 256;
+    static constexpr int W_ITERS = (WT / 4 + 255) / 256;
+    static constexpr int BN_MAXC = 256;  // pre-BN scale/shift of up to 256 input channels live in LDS
+    static constexpr size_t LDS_BYTES = size_t(2 * STAGE + 2 * BN_MAXC) * 4;
+    // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
+    // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
+    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0);
+    // register budget per lane: 168 at three workgroups per CU, 256 at two
+    // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
+    static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
+    static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
+                  "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
+    static_assert(COUT_T % 32 == 0 || (TAIL16 && !SPLITK && CK == 4 && TW == 32 && NIMG == 1),
+                  "cout tile must be a multiple of the 32-row MFMA tile (+ one 16-row strip on the 32-pixel-row tiles)");
+    static_assert(CK % 2 == 0, "the f32 MFMA consumes two k values per step");
+    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's 160 KiB LDS");
+};
+
+// ---- pieces of the main loop, as force-inlined functions over register arrays -----------
+// One "item" is one staged element per thread: items [0, X_ITERS) are input-tile floats,
+// items [X_ITERS, X_ITERS + W_ITERS) are float4s of the weight slice.
+template <class C>
+struct StageRegs {
+    float xv[C::X_ITERS];
+    f32x4 wv[C::W_ITERS];
+    float bn_s[C::X_ITERS], bn_t[C::X_ITERS];
+};
+
+// Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
+// padding elements read element 0 and are zeroed at write time): a branch around a load makes
+// the compiler wait for each one separately.
+template <class C, int T>
+__device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
+                                           const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
+                                           StageRegs<C>& r, float* st_dst) {
+    if constexpr (T < C::X_ITERS) {
+        const int c = cb + (tid + T * 256) / C::PLANE;
+        const bool ok = goff[T] != INVALID_OFF && c < a.cin;
+        // wave-uniform base; one unconditional load per lane (masked lanes read a valid element)
+        const float* const base = a.in + size_t(cb < a.cin ? cb : 0) * HWin;
+        r.xv[T] = base[ok ? goff[T] : 0u];
+        if (a.pre_scale != nullptr) {  // this element's BatchNorm scale / shift from the LDS copy
+            const int cc = c < a.cin_pad ? c : 0;
+            r.bn_s[T] = sbn[cc];
+            r.bn_t[T] = sbn[C::BN_MAXC + cc];
+        }
+    } else {
+        constexpr int I = T - C::X_ITERS;
+        const float* const base = a.w + size_t(cb) * a.cout_pad;  // wave-uniform
+        r.wv[I] = *reinterpret_cast<const f32x4*>(base + (woff_g[I] != INVALID_OFF ? woff_g[I] : 0u));
+    }
+}
+
+// BatchNorm + ReLU (pre-activation block), zero padding AFTER the activation, then the LDS write
+template <class C, int T>
+__device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, float* st,
+                                           const unsigned (&goff)[C::X_ITERS], const StageRegs<C>& r) {
+    if constexpr (T < C::X_ITERS) {
+        const int e = tid + T * 256;
+        const int c = cb + e / C::PLANE;
+        const bool ok = goff[T] != INVALID_OFF && c < a.cin;
+        float v = r.xv[T];
+        if (a.pre_scale != nullptr) v = fmaxf(fmaf(v, r.bn_s[T], r.bn_t[T]), 0.f);
+        v = ok ? v : 0.f;
+        if (e < C::XT) st[e] = v;
+    } else {
+        constexpr int I = T - C::X_ITERS;
+        const int f = tid + I * 256;
+        if (f < C::WT / 4) reinterpret_cast<f32x4*>(st + C::XT_PAD)[f] = r.wv[I];
+    }
+}
+
+// The MFMAs of one K-chunk out of LDS stage `st`.  Operands of k-step s+1 are fetched from LDS
+// while the MFMAs of step s issue.  With STAGE_NEXT the staging of the next chunk (cb_next) is
+// spread over the k-steps so its address arithmetic, loads, BatchNorm and LDS writes run in the
+// shadow of the 64-cycle MFMAs: loads are issued during the first half of the steps, written to
+// the other stage `st_next` half a chunk (~9k cycles) later.
+template <class C, bool STAGE_NEXT>
+__device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st, float* st_next, int cb_next, int tid,
+                                              unsigned HWin, const float* sbn, int woff, const int (&pixoff)[C::NT],
+                                              const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
+                                              StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT], int woff16,
+                                              const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16]) {
+    constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
+    constexpr int HALF = C::KSTEPS / 2;
+    float av[2][C::MT], bv[2][C::NT];
+    float a16 = 0.f, b16[C::NT16];  // 16-row strip: operands of one tap's four channels (two k-steps)
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) av[0][m] = st[woff + m * 32];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) bv[0][n] = st[pixoff[n]];
+    static_for<0, C::KSTEPS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int nx = ks + 1;
+        if constexpr (nx < C::KSTEPS) {
+            constexpr int tap = nx / (C::CKW / 2), cp = nx % (C::CKW / 2);
+            constexpr int toff = (tap / C::KS) * C::PW + (tap % C::KS);
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) av[nx & 1][m] = st[woff + (tap * C::CK + 2 * cp) * C::COUT_T + m * 32];
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n) bv[nx & 1][n] = st[2 * cp * C::PLANE + pixoff[n] + toff];
+        }
+        if constexpr (C::TAIL16 && (ks & 1) == 0) {
+            // the strip's A (16 channels x 4 k) and B (4 k x 16 pixels) fragments of this tap, used
+            // by the 16x16x4 MFMAs of the tap's second k-step
+            constexpr int tap16 = ks / 2;
+            constexpr int toff16 = (tap16 / C::KS) * C::PW + (tap16 % C::KS);
+            a16 = st[woff16 + tap16 * C::CK * C::COUT_T];
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j) b16[j] = st[pixoff16[j] + toff16];
+        }
+        // two MFMAs first, then this step's share of the staging work, then the rest: the side
+        // work's LDS / VMEM operations complete in the shadow of the remaining MFMAs instead of
+        // being waited for at the next step's lgkmcnt(0)
+        constexpr int LEAD = (C::MT * C::NT >= 4) ? 2 : 1;
+        static_for<0, C::MT * C::NT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int m = i / C::NT, n = i % C::NT;
+            if constexpr (i < LEAD)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAGE_NEXT) {
+            static_for<0, T_TOT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+#if !defined(MVLM_ABLATE_NO_LOADS)
+                if constexpr ((t * HALF) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r, st_next);
+#endif
+#if !defined(MVLM_ABLATE_NO_WRITES)
+                if constexpr (HALF + (t * HALF) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
+#endif
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // two waves share a SIMD (two workgroups per CU): the one inside its MFMA run keeps the pipe
+        __builtin_amdgcn_s_setprio(1);
+        static_for<0, C::MT * C::NT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int m = i / C::NT, n = i % C::NT;
+            if constexpr (i >= LEAD)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+        });
+        if constexpr (C::TAIL16 && (ks & 1) == 1) {
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j) acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16[j], acc16[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // keep each step's LDS prefetch and side work inside its own MFMA shadow
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// Software-pipelined main loop, one workgroup (4 waves, one per SIMD) per CU-resident tile:
+//   while the MFMAs of K-chunk c run out of LDS stage c&1, the global loads of chunk c+1 are
+//   in flight into registers; after the MFMAs they get their BatchNorm+ReLU and are written to
+//   the other stage; ONE barrier per chunk.  The kernel may use the whole 512-register file
+//   (launch bounds 256,1), so nothing spills and the 128 accumulators stay in registers.
+template <class C, bool AMAX>
+__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                           const int cout_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    // XCD-aware tile order: consecutive block ids land on different XCDs, so give every
+    // XCD a contiguous run of tiles (cout tiles of one pixel tile share its input in L2).
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int ct = lid % cout_tiles;
+    const int pt = lid / cout_tiles;
+    const int tx = pt % tiles_x;
+    const int ty = (pt / tiles_x) % tiles_y;
+    const int tb = pt / (tiles_x * tiles_y);
+    const int x0 = tx * C::TW, y0 = ty * C::TRI, b0 = tb * C::NIMG, co0 = ct * C::COUT_T;
+
+    const int H = a.H, W = a.W;
+    const int Hin = a.up_in ? (H >> 1) : H, Win = a.up_in ? (W >> 1) : W;
+    const unsigned HWin = unsigned(Hin) * unsigned(Win);
+
+    // ---- per-thread staging plan for the input tile (fixed across K-chunks) ----------
+    unsigned goff[C::X_ITERS];
+#pragma unroll
+    for (int i = 0; i < C::X_ITERS; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / C::PLANE;
+        const int rem = e - c * C::PLANE;
+        const int img = rem / (C::PH * C::PW);
+        const int rem2 = rem - img * (C::PH * C::PW);
+        const int yy = rem2 / C::PW;
+        const int xx = rem2 - yy * C::PW;
+        const int y = y0 + yy - C::HALO, x = x0 + xx - C::HALO, b = b0 + img;
+        const bool ok = (e < C::XT) && y >= 0 && y < H && x >= 0 && x < W && b < a.B;
+        const int ys = a.up_in ? (y >> 1) : y, xs = a.up_in ? (x >> 1) : x;
+        goff[i] = ok ? (unsigned(b * a.in_ctot + a.in_coff + c) * HWin + unsigned(ys * Win + xs)) : INVALID_OFF;
+    }
+    // weight slice: float4 index f -> (tap, c, cout4); the source offset is chunk-invariant
+    // apart from the channel base
+    unsigned woff_g[C::W_ITERS];
+#pragma unroll
+    for (int i = 0; i < C::W_ITERS; ++i) {
+        const int f = tid + i * 256;
+        const int row = f / (C::COUT_T / 4);
+        const int c4 = f - row * (C::COUT_T / 4);
+        const int tap = row / C::CK;
+        const int c = row - tap * C::CK;
+        woff_g[i] = (f < C::WT / 4) ? unsigned((tap * a.cin_pad + c) * a.cout_pad + co0 + c4 * 4) : INVALID_OFF;
+    }
+
+    // ---- per-lane operand offsets inside a stage ---------------------------------------
+    int pixoff[C::NT];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) {
+        const int p = (C::SPLITK ? 0 : wave * (C::PIX_T / 4)) + n * 32 + l31;
+        const int x = p % C::TW;
+        const int rr = p / C::TW;
+        const int yl = rr % C::TRI;
+        const int img = rr / C::TRI;
+        pixoff[n] = (img * C::PH + yl) * C::PW + x + half * C::PLANE + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0) +
+                    (C::SPLITK ? wave * C::CKW * C::PLANE : 0);
+    }
+    const int woff = C::XT_PAD + half * C::COUT_T + l31 + (C::SPLITK ? wave * C::CKW * C::COUT_T : 0);
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < C::NT; ++n) acc[m][n] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // 16-row strip (TAIL16): lane l multiplies channel 32*MT + (l & 15) with k = l >> 4 of a tap's four
+    // channels; result register i of column group j is channel 32*MT + 4*(l >> 4) + i at pixel 16*j + (l & 15)
+    const int q16 = lane >> 4, i16 = lane & 15;
+    const int woff16 = C::XT_PAD + q16 * C::COUT_T + C::MT * 32 + i16;
+    int pixoff16[C::NT16];
+    f32x4 acc16[C::NT16];
+#pragma unroll
+    for (int j = 0; j < C::NT16; ++j) {
+        const int p = wave * (C::PIX_T / 4) + j * 16 + i16;
+        pixoff16[j] = (p / C::TW % C::TRI) * C::PW + p % C::TW + q16 * C::PLANE + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0);
+        acc16[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // the consumer-side BatchNorm (scale, shift per input channel) is read from LDS
+    float* sbn = smem + 2 * C::STAGE;
+    if (a.pre_scale != nullptr) {
+        for (int i = tid; i < a.cin_pad; i += 256) {
+            sbn[i] = a.pre_scale[i];
+            sbn[C::BN_MAXC + i] = a.pre_shift[i];
+        }
+        __syncthreads();
+    }
+    StageRegs<C> regs;
+    constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value>(a, 0, tid, HWin, sbn, goff, woff_g, regs, smem); });
+    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, 0, tid, smem, goff, regs); });
+    __syncthreads();
+
+    int cur = 0;
+    for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
+#if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
+        compute_chunk<C, false>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+                                goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+#else
+        compute_chunk<C, true>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+                               goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+#endif
+#if !defined(MVLM_ABLATE_NO_BARRIER)
+        __syncthreads();  // next stage complete; everybody is done reading this one
+#endif
+        cur ^= 1;
+    }
+    compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+
+#if defined(MVLM_ABLATE_NO_EPILOGUE)  // timing experiment only: wrong results
+    {
+        float sacc = 0.f;
+        static_for<0, C::MT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[m][n][r];
+        });
+        if (sacc == 123.456f) a.out[0] = sacc;
+        return;
+    }
+#endif
+    if constexpr (C::SPLITK) {
+        // add the four waves' partial tiles in wave order (deterministic), wave 0 finishes alone
+        __syncthreads();  // every wave is done reading the stages: reuse them as the exchange buffer
+        float* red = smem;
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+    }
+
+    // ---------------------------------- epilogue ---------------------------------------
+    // Addresses are wave-uniform channel bases (scalar registers) + one 32-bit per-lane offset per
+    // tensor and pixel column, so an element costs a load/add/store, not 64-bit vector arithmetic.
+    const unsigned HW = unsigned(H) * unsigned(W);
+    bool lane_ok[C::NT];
+    int ppix[C::NT];
+    unsigned o_raw[C::NT], o_r1[C::NT], o_r2[C::NT], o_out[C::NT], o_skip[C::NT];
+    // fused 2x2 max-pool: the rows of a pair are two pixel registers of one lane (n, n+1), the columns two
+    // neighbouring lanes, so it needs 32-pixel tile rows, one image per tile and an even row count per wave
+    constexpr bool CAN_POOL = !C::SPLITK && C::TW == 32 && C::NIMG == 1 && C::NT % 2 == 0;
+    unsigned o_pool[C::NT / 2 > 0 ? C::NT / 2 : 1];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) {
+        const int p = (C::SPLITK ? 0 : wave * (C::PIX_T / 4)) + n * 32 + l31;
+        const int rr = p / C::TW;
+        const int b = b0 + rr / C::TRI;
+        const int y = y0 + rr % C::TRI, x = x0 + p % C::TW;
+        lane_ok[n] = C::NIMG == 1 ? true : (b < a.B);
+        const unsigned bb = lane_ok[n] ? unsigned(b) : 0u;
+        const unsigned pix = unsigned(y * W + x);
+        const unsigned h4 = 4u * unsigned(half);
+        ppix[n] = int(pix);
+        o_raw[n] = (bb * a.raw_ctot + a.raw_coff + h4) * HW + pix;
+        o_r1[n] = (bb * a.res1_ctot + a.res1_coff + h4) * HW + pix;
+        o_r2[n] = (bb * a.res2_ctot + a.res2_coff + h4) * HW + pix;
+        if constexpr (CAN_POOL)
+            if ((n & 1) == 0) o_pool[n / 2] = (bb * a.pool_ctot + a.pool_coff + h4) * (HW / 4) + unsigned((y >> 1) * (W >> 1) + (x >> 1));
+        if (!a.up_out) {
+            o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * HW + pix;
+            o_skip[n] = 0;
+        } else if (a.up_out == 2) {
+            const unsigned o2 = unsigned(2 * y + a.sub_y) * unsigned(2 * W) + unsigned(2 * x + a.sub_x);
+            o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * (4u * HW) + o2;
+            o_skip[n] = 0;
+            ppix[n] = int(o2);  // the argmax runs over full-resolution pixel indices
+        } else {
+            const unsigned o2 = unsigned(2 * y) * unsigned(2 * W) + unsigned(2 * x);
+            o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * (4u * HW) + o2;
+            o_skip[n] = (bb * a.skip_ctot + a.skip_coff + h4) * (4u * HW) + o2;
+        }
+    }
+    // Channels are walked in groups of four accumulator registers (= four consecutive channels
+    // per half-wave).  The residual values of group g+1 are loaded (unconditionally, clamped
+    // addresses) before group g is finished and stored, so a load's latency is paid once per
+    // group of 4*NT elements instead of once per element, and the feature flags cost one
+    // wave-uniform branch per group.
+    constexpr int GE = 4 * C::NT;       // elements per group
+    constexpr int NG = C::MT * 4;       // groups per wave
+    auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;  // every channel row of this tile exists
+        float resv[2][GE];
+        auto group_base = [&](int g) { return co0 + (g >> 2) * 32 + 8 * (g & 3); };  // wave-uniform first channel
+        auto load_group = [&](auto gc, float (&dst)[GE]) {
+            constexpr int g = decltype(gc)::value;
+            if (a.res1) {
+                const int cs0 = group_base(g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // clamp the row so padded channel rows still read inside the tensor
+                    const int cs = (FULL || cs0 + j + 4 < a.cout) ? cs0 + j : 0;
+                    const float* const p1 = a.res1 + size_t(cs) * HW;
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) dst[j * C::NT + n] = p1[o_r1[n]];
+                }
+                if (a.res2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cs = (FULL || cs0 + j + 4 < a.cout) ? cs0 + j : 0;
+                        const float* const p2 = a.res2 + size_t(cs) * HW;
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) dst[j * C::NT + n] += p2[o_r2[n]];
+                    }
+                }
+            }
+        };
+        load_group(std::integral_constant<int, 0>{}, resv[0]);
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int m = g >> 2, rg = g & 3;
+            if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, resv[(g + 1) & 1]);
+            const int cs0 = group_base(g);
+            float vals[GE];
+            bool okc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = cs0 + j + 4 * half;
+                okc[j] = FULL || co < a.cout;
+                const int coc = okc[j] ? co : 0;
+                const float bias = a.bias ? a.bias[coc] : 0.f;
+                const float ps = a.post_scale ? a.post_scale[coc] : 1.f;
+                const float pt = a.post_scale ? a.post_shift[coc] : 0.f;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) {
+                    float v = acc[m][n][4 * rg + j];
+                    if (a.bias) v += bias;
+                    if (a.post_scale) v = fmaxf(fmaf(v, ps, pt), 0.f);
+                    vals[j * C::NT + n] = v;
+                }
+            }
+            if (a.out_raw) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* const p = a.out_raw + size_t(cs0 + j) * HW;
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+                        if (okc[j] && lane_ok[n]) p[o_raw[n]] = vals[j * C::NT + n];
+                }
+            }
+            if (a.res1) {
+#pragma unroll
+                for (int e = 0; e < GE; ++e) vals[e] += resv[g & 1][e];
+            }
+            if constexpr (CAN_POOL) {
+                if (a.pool_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* const p = a.pool_out + size_t(cs0 + j) * (HW / 4);
+#pragma unroll
+                        for (int q = 0; q < C::NT / 2; ++q) {
+                            const float v2 = fmaxf(vals[j * C::NT + 2 * q], vals[j * C::NT + 2 * q + 1]);
+                            const int vi = __float_as_int(v2);
+                            const float other = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xf, 0xf, false));  // lane ^ 1
+                            if (okc[j] && (l31 & 1) == 0) p[o_pool[q]] = fmaxf(v2, other);
+                        }
+                    }
+                }
+            }
+            if (a.out) {
+                if (a.up_out != 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* const p = a.out + size_t(cs0 + j) * HW * (a.up_out ? 4 : 1);
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n)
+                            if (okc[j] && lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
+                    }
+                } else {
+                    const unsigned W2 = 2u * unsigned(W);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the row's skip loads first, then its 2x2 scatter
+                        const int cs = okc[j] ? cs0 + j : 0;
+                        const float* const ps = a.skip + size_t(cs) * HW * 4;
+                        float* const p = a.out + size_t(cs0 + j) * HW * 4;
+                        float2 s0[C::NT], s1[C::NT];
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) {
+                            s0[n] = *reinterpret_cast<const float2*>(ps + o_skip[n]);
+                            s1[n] = *reinterpret_cast<const float2*>(ps + o_skip[n] + W2);
+                        }
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) {
+                            if (okc[j] && lane_ok[n]) {
+                                const float v = vals[j * C::NT + n];
+                                *reinterpret_cast<float2*>(p + o_out[n]) = make_float2(v + s0[n].x, v + s0[n].y);
+                                *reinterpret_cast<float2*>(p + o_out[n] + W2) = make_float2(v + s1[n].x, v + s1[n].y);
+                            }
+                        }
+                    }
+                }
+            }
+        });
+    };
+    if (co0 + C::COUT_T <= a.cout)
+        epilogue(std::true_type{});
+    else
+        epilogue(std::false_type{});
+
+    // ---- the 16-row strip: plain conv + bias layers only (conv6, conv10, conv11; checked on the host) ----
+    int pix16[C::NT16];            // output pixel index of column group j (full resolution for up_out == 2)
+    float val16[C::NT16][4];       // acc + bias, kept for the fused argmax
+    bool ok16[4];
+    if constexpr (C::TAIL16) {
+        const unsigned b = unsigned(b0);
+#pragma unroll
+        for (int j = 0; j < C::NT16; ++j) {
+            const int p = wave * (C::PIX_T / 4) + j * 16 + i16;
+            const int y = y0 + p / C::TW, x = x0 + p % C::TW;
+            pix16[j] = a.up_out == 2 ? (2 * y + a.sub_y) * (2 * W) + 2 * x + a.sub_x : y * W + x;
+        }
+        const unsigned plane = a.up_out == 2 ? 4u * HW : HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + C::MT * 32 + 4 * q16 + i;
+            ok16[i] = co < a.cout;
+            const int coc = ok16[i] ? co : 0;
+            const float bias = a.bias ? a.bias[coc] : 0.f;
+            float* const po = a.out ? a.out + (size_t(b) * a.out_ctot + a.out_coff + coc) * plane : nullptr;
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j) {
+                val16[j][i] = acc16[j][i] + bias;
+                if (po && ok16[i]) po[pix16[j]] = val16[j][i];
+            }
+        }
+    }
+
+    if constexpr (AMAX) {
+        // Fused heatmap argmax (paulsenpredictor.py:123): conv11 has no residual / post-BN, so
+        // the heatmap value is acc + bias.  First maximum in row-major order wins ties.
+        static_for<0, C::MT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int coc = co < a.cout ? co : 0;
+                const float bias = a.bias ? a.bias[coc] : 0.f;
+                // value first: max over this lane's pixels, then over the 32 lanes of the half-wave with
+                // DPP-modified v_max (row_shr 1, 2, 4, 8 leave each 16-lane row's maximum in its lane 15,
+                // row_bcast15 hands it to the next row: lanes 31 / 63 hold the half-waves' maxima)
+                float vals[C::NT];
+                float best_v = -INFINITY;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) {
+                    vals[n] = lane_ok[n] ? acc[m][n][r] + bias : -INFINITY;
+                    best_v = fmaxf(best_v, vals[n]);
+                }
+                auto dpp_f = [](float x, auto ctrl_c, auto rows_c) {
+                    const int xi = __float_as_int(x);
+                    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false));
+                };
+                auto dpp_i = [](int x, auto ctrl_c, auto rows_c) {
+                    return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false);
+                };
+                using SHR1 = std::integral_constant<int, 0x111>;
+                using SHR2 = std::integral_constant<int, 0x112>;
+                using SHR4 = std::integral_constant<int, 0x114>;
+                using SHR8 = std::integral_constant<int, 0x118>;
+                using BC15 = std::integral_constant<int, 0x142>;
+                using ALL = std::integral_constant<int, 0xf>;
+                using ODD = std::integral_constant<int, 0xa>;
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR1{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR2{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR4{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR8{}, ALL{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, BC15{}, ODD{}));
+                const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 31));
+                const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 63));
+                best_v = half ? m_hi : m_lo;
+                // then the first pixel (row-major) that attains it
+                int best_i = 0x7fffffff;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) best_i = min(best_i, vals[n] == best_v ? ppix[n] : 0x7fffffff);
+                best_i = min(best_i, dpp_i(best_i, SHR1{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, SHR2{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, SHR4{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, SHR8{}, ALL{}));
+                best_i = min(best_i, dpp_i(best_i, BC15{}, ODD{}));
+                if (l31 == 31 && co < a.cout && b0 < a.B) {
+                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
+                    a.amax_val[o] = best_v;
+                    a.amax_idx[o] = best_i;
+                }
+            }
+        });
+        if constexpr (C::TAIL16) {
+            // strip: a 16-lane row holds 16 pixels of channels 4*q16 + i; rows reduce on their own
+            using SHR1 = std::integral_constant<int, 0x111>;
+            using SHR2 = std::integral_constant<int, 0x112>;
+            using SHR4 = std::integral_constant<int, 0x114>;
+            using SHR8 = std::integral_constant<int, 0x118>;
+            auto dpp_f = [](float x, auto ctrl_c) {
+                const int xi = __float_as_int(x);
+                return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl_c)::value, 0xf, 0xf, false));
+            };
+            auto dpp_i = [](int x, auto ctrl_c) { return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, 0xf, 0xf, false); };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float best_v = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < C::NT16; ++j) best_v = fmaxf(best_v, val16[j][i]);
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR1{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR2{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR4{}));
+                best_v = fmaxf(best_v, dpp_f(best_v, SHR8{}));  // lane 15 of every row: the row's maximum
+                const int bi = __float_as_int(best_v);
+                const int r0 = __builtin_amdgcn_readlane(bi, 15), r1 = __builtin_amdgcn_readlane(bi, 31);
+                const int r2 = __builtin_amdgcn_readlane(bi, 47), r3 = __builtin_amdgcn_readlane(bi, 63);
+                best_v = __int_as_float(q16 == 0 ? r0 : q16 == 1 ? r1 : q16 == 2 ? r2 : r3);
+                int best_i = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < C::NT16; ++j) best_i = min(best_i, val16[j][i] == best_v ? pix16[j] : 0x7fffffff);
+                best_i = min(best_i, dpp_i(best_i, SHR1{}));
+                best_i = min(best_i, dpp_i(best_i, SHR2{}));
+                best_i = min(best_i, dpp_i(best_i, SHR4{}));
+                best_i = min(best_i, dpp_i(best_i, SHR8{}));
+                const int co = co0 + C::MT * 32 + 4 * q16 + i;
+                if (i16 == 15 && co < a.cout && b0 < a.B) {
+                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
+                    a.amax_val[o] = best_v;
+                    a.amax_idx[o] = best_i;
+                }
+            }
+        }
+    }
+}
+
+// ---- variant table ---------------------------------------------------------------------
+// id, name, instantiation.  W >= 32 uses row-segment tiles; smaller levels fold rows /
+// images into the 32-pixel MFMA column.
+template <class C>
+int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
+    const int tiles_x = a.W / C::TW, tiles_y = a.H / C::TRI;
+    const int tiles_b = (a.B + C::NIMG - 1) / C::NIMG;
+    const int cout_tiles = a.cout_pad / C::COUT_T;
+    MVLM_REQUIRE(ctx, a.W % C::TW == 0 && a.H % C::TRI == 0, "conv: spatial size not a multiple of the tile");
+    MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
+    MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
+    MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
+    if (C::TAIL16)
+        MVLM_REQUIRE(ctx, !a.res1 && !a.res2 && !a.out_raw && !a.post_scale && a.up_out != 1 && !a.pool_out,
+                     "conv: the 80-channel tiles serve plain conv + bias layers only");
+    if (a.amax_val) {
+        MVLM_REQUIRE(ctx, C::NIMG == 1, "conv: fused argmax needs one image per tile");
+        MVLM_REQUIRE(ctx, a.amax_part0 >= 0 && a.amax_part0 + tiles_x * tiles_y * 4 <= a.amax_parts,
+                     "conv: argmax partial range mismatch");
+        MVLM_REQUIRE(ctx, !a.res1 && !a.post_scale && a.up_out != 1, "conv: fused argmax expects a plain conv + bias layer");
+    }
+    const long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
+    MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
+    static bool attr_set = false;
+    if (!attr_set) {
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS != 1)
+            MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+        attr_set = true;
+    }
+    if (a.amax_val) {
+        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS != 1) {
+            hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream,
+                               a, tiles_x, tiles_y, cout_tiles);
+        } else {
+            return ctx->fail("conv: fused argmax is only built for the 8x32-pixel tile variants");
+        }
+    } else {
+        hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream, a,
+                           tiles_x, tiles_y, cout_tiles);
+    }
+    MVLM_CHECK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+
+}  // namespace
+#endif
