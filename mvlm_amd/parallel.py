@@ -46,6 +46,21 @@ def broadcast_array(arr: np.ndarray | None, src: int = 0) -> np.ndarray:
     return box[0]
 
 
+def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0) -> np.ndarray:
+    """Broadcast a small int32 table (the RANSAC draws) as ONE tensor collective - no pickling."""
+    if not is_distributed():
+        return arr
+    import torch
+    import torch.distributed as dist
+
+    on_gpu = dist.get_backend() != "gloo"
+    t = torch.zeros(shape, dtype=torch.int32, device=device if on_gpu else "cpu")
+    if dist.get_rank() == src:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)))
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
 def all_gather_views(local, n_total: int):
     """local: torch tensor [NL, n_local, 3] on this rank's device -> [NL, n_total, 3] in view order."""
     if not is_distributed():

@@ -176,24 +176,17 @@ class Pipeline(abc.ABC, TimeMixin):
         self._say("Landmarks [0] - From Heatmaps: ", self.p_time(self.timings["lines"]))
 
         t0 = time.time()
-        draw_fn = None
+        draws_fn = None
         if sharded:
-            # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference),
-            # everybody uses the same table
-            table = {}
+            # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) from the survivor
+            # counts every rank computed, and broadcasts the [NL, 8] index table
+            def draws_fn(counts):
+                draws = e3.draw_ransac_indices(counts) if rank == 0 else None
+                return parallel.broadcast_int32(draws, (len(counts), 8), maxima.device)
 
-            def draw_fn(lm, k, _t=table):
-                return _t[lm]
-
-            counts_probe = self._survivor_counts(maxima)
-            if rank == 0:
-                for lm, k in enumerate(counts_probe):
-                    if k >= 3:
-                        table[lm] = np.random.randint(0, int(k), size=8)  # == np.random.choice(range(k), 8)
-            table.update(parallel.broadcast_array(table if rank == 0 else None))
         if self.visualize_rays:
             self._rays = (mesh, starts.cpu().numpy(), ends.cpu().numpy())
-        out, err, _ = e3.consensus_device(maxima, starts, ends, draw_fn=draw_fn)
+        out, err, _ = e3.consensus_device(maxima, starts, ends, draws_fn=draws_fn)
         error = e3.mean_error(err.cpu().numpy())
         self.timings["consensus"] = time.time() - t0
         self._say("Landmarks [1] - From View Lines: ", self.p_time(self.timings["consensus"]))
@@ -206,23 +199,6 @@ class Pipeline(abc.ABC, TimeMixin):
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error
         return landmarks, error
-
-    def _survivor_counts(self, maxima):
-        """Per-landmark count of lines that pass the filter (needed before the host draws)."""
-        import ctypes as C
-        import torch
-
-        e3 = self.estimator_3d
-        nl, n = int(maxima.shape[0]), int(maxima.shape[1])
-        mask = torch.empty((nl, n), dtype=torch.uint8, device=maxima.device)
-        count = torch.empty((nl,), dtype=torch.int32, device=maxima.device)
-        mode = {"quantile": 0, "absolute": 1}.get(e3.mode)
-        if mode is None:
-            raise ValueError(f"Unknown mode for line matching in Estimator: {e3.mode}")
-        e3.ctx.check(e3.ctx.lib.mvlm_consensus_mask(
-            e3.ctx.handle, C.c_void_p(maxima.data_ptr()), n, nl, mode, float(e3.threshold_quantile),
-            float(e3.threshold_absolute), C.c_void_p(mask.data_ptr()), C.c_void_p(count.data_ptr())), ValueError)
-        return count.cpu().numpy()
 
     def predict_files(self, files, prefetch: int = 2):
         """``predict_one_file`` over many scans, yielding ``(file, landmarks | None)`` in order.

@@ -52,8 +52,24 @@ class HipEstimator3D:
             C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr())))
         return starts, ends
 
-    def consensus_device(self, landmarks_dev, starts, ends, draw_fn=None):
-        """Filter + one-shot RANSAC + LSQ on device.  Returns (landmarks f64[NL,3] tensor,
+    def draw_ransac_indices(self, counts: np.ndarray) -> np.ndarray:
+        """The reference draws once per landmark with >= 3 surviving lines, in landmark order, from the
+        global numpy RNG (estimator3d.py:105, :174-179).  counts int[NL] -> draws int32[NL,8]."""
+        draws = np.zeros((len(counts), 8), dtype=np.int32)
+        for lm, k in enumerate(counts):
+            k = int(k)
+            if k < 3:
+                if self.verbose:
+                    print("Not enough points for good estimate of landmark lm_no", lm, k)
+                continue
+            # np.random.choice(range(k), 8, replace=True) (estimator3d.py:105) consumes the global
+            # RNG through randint(0, k, size=8); calling that directly skips building range(k)
+            draws[lm] = np.random.randint(0, k, size=8)
+        return draws
+
+    def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None):
+        """Filter + one-shot RANSAC + LSQ on device.  ``draws_fn(counts) -> int32[NL,8]`` replaces the local
+        RNG draw (the sharded pipeline broadcasts rank 0's).  Returns (landmarks f64[NL,3] tensor,
         per-landmark error f64[NL] tensor, counts int32[NL] numpy)."""
         torch, dev = self._torch()
         if self.mode not in _MODES:
@@ -66,18 +82,9 @@ class HipEstimator3D:
             float(self.threshold_quantile), float(self.threshold_absolute), C.c_void_p(mask.data_ptr()),
             C.c_void_p(count.data_ptr())), ValueError)
         counts = count.cpu().numpy()
-        # the reference draws once per landmark with >= 3 surviving lines, in landmark
-        # order, from the global numpy RNG (estimator3d.py:105, :174-179)
-        draws = np.zeros((nl, 8), dtype=np.int32)
-        for lm in range(nl):
-            k = int(counts[lm])
-            if k < 3:
-                if self.verbose:
-                    print("Not enough points for good estimate of landmark lm_no", lm, k)
-                continue
-            # np.random.choice(range(k), 8, replace=True) (estimator3d.py:105) consumes the global
-            # RNG through randint(0, k, size=8); calling that directly skips building range(k)
-            draws[lm] = draw_fn(lm, k) if draw_fn is not None else np.random.randint(0, k, size=8)
+        draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(counts), dtype=np.int32)
+        if draws.shape != (nl, 8):
+            raise ValueError(f"RANSAC draws must be [{nl}, 8], got {draws.shape}")
         draws_dev = torch.from_numpy(draws).to(dev)
         out = torch.empty((nl, 3), dtype=torch.float64, device=dev)
         err = torch.empty((nl,), dtype=torch.float64, device=dev)

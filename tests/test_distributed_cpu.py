@@ -27,7 +27,10 @@ def _worker(rank, world, port, n_total, nl, q):
     got = parallel.all_gather_views(full[:, lo:hi].contiguous(), n_total)
     poses = np.arange(12.0).reshape(4, 3) if rank == 0 else None
     poses = parallel.broadcast_array(poses)
-    q.put((rank, bool(torch.equal(got, full)), poses.tolist()))
+    draws = np.arange(nl * 8, dtype=np.int32).reshape(nl, 8) * 3 if rank == 0 else None
+    draws = parallel.broadcast_int32(draws, (nl, 8), torch.device("cpu"))  # the RANSAC index table of rank 0
+    ok_draws = draws.dtype == np.int32 and np.array_equal(draws, np.arange(nl * 8).reshape(nl, 8) * 3)
+    q.put((rank, bool(torch.equal(got, full)) and ok_draws, poses.tolist()))
     dist.destroy_process_group()
 
 
