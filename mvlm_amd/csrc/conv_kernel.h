@@ -441,21 +441,25 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             constexpr int m = g >> 2, rg = g & 3;
             if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, resv[(g + 1) & 1]);
             const int cs0 = group_base(g);
+            // bias / post-BN parameters of this lane's four channels: ONE 16-byte load each (the
+            // vectors are padded to cout_pad, so rows beyond cout read zeros, never out of bounds)
+            const int cl = cs0 + 4 * half;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + cl);
+            if (a.post_scale) {
+                ps4 = *reinterpret_cast<const f32x4*>(a.post_scale + cl);
+                pt4 = *reinterpret_cast<const f32x4*>(a.post_shift + cl);
+            }
             float vals[GE];
             bool okc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = cs0 + j + 4 * half;
-                okc[j] = FULL || co < a.cout;
-                const int coc = okc[j] ? co : 0;
-                const float bias = a.bias ? a.bias[coc] : 0.f;
-                const float ps = a.post_scale ? a.post_scale[coc] : 1.f;
-                const float pt = a.post_scale ? a.post_shift[coc] : 0.f;
+                okc[j] = FULL || cl + j < a.cout;
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n) {
                     float v = acc[m][n][4 * rg + j];
-                    if (a.bias) v += bias;
-                    if (a.post_scale) v = fmaxf(fmaf(v, ps, pt), 0.f);
+                    if (a.bias) v += bias4[j];
+                    if (a.post_scale) v = fmaxf(fmaf(v, ps4[j], pt4[j]), 0.f);
                     vals[j * C::NT + n] = v;
                 }
             }
