@@ -79,6 +79,9 @@ struct ConvArgs {
     // pool_out is [B][pool_ctot][H/2][W/2]; `out` may be null when only the pooled tensor is consumed
     float* pool_out = nullptr;
     int pool_ctot = 0, pool_coff = 0;
+    // -DMVLM_CONV_TIMING builds only (tools/conv_phase_timing.py): u64[4] = summed cycles of wave 0 in
+    // prologue / K loop / epilogue, number of workgroups
+    unsigned long long* timing = nullptr;
 };
 
 struct ConvProfileRec {

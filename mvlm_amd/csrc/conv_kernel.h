@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     const int tb = pt / (tiles_x * tiles_y);
     const int x0 = tx * C::TW, y0 = ty * C::TRI, b0 = tb * C::NIMG, co0 = ct * C::COUT_T;
 
+#if defined(MVLM_CONV_TIMING)
+    const long long t_start = clock64();
+#endif
     const int H = a.H, W = a.W;
     const int Hin = a.up_in ? (H >> 1) : H, Win = a.up_in ? (W >> 1) : W;
     const unsigned HWin = unsigned(Hin) * unsigned(Win);
@@ -314,6 +317,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, 0, tid, smem, goff, regs); });
     __syncthreads();
 
+#if defined(MVLM_CONV_TIMING)
+    const long long t_loop = clock64();
+#endif
     int cur = 0;
     for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
 #if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
@@ -329,6 +335,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         cur ^= 1;
     }
     compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+#if defined(MVLM_CONV_TIMING)
+    const long long t_epi = clock64();
+#endif
 
 #if defined(MVLM_ABLATE_NO_EPILOGUE)  // timing experiment only: wrong results
     {
@@ -408,8 +417,19 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     // wave-uniform branch per group.
     constexpr int GE = 4 * C::NT;       // elements per group
     constexpr int NG = C::MT * 4;       // groups per wave
-    auto epilogue = [&](auto full_c) {
+    auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;  // every channel row of this tile exists
+        // The tensors may share storage (a block adds into its own residual slice in place, the
+        // hourglass adds into its skip tensor), but only element-wise: a value is stored to the
+        // address it was loaded from, never to another group's.  __restrict__ tells the compiler
+        // exactly that, so it stops draining the memory pipeline (s_waitcnt vmcnt(0)) between one
+        // group's stores and the next group's loads.
+        const float* __restrict__ const t_res1 = a.res1;
+        const float* __restrict__ const t_res2 = a.res2;
+        const float* __restrict__ const t_skip = a.skip;
+        float* __restrict__ const t_raw = a.out_raw;
+        float* __restrict__ const t_out = a.out;
+        float* __restrict__ const t_pool = a.pool_out;
         float resv[2][GE];
         auto group_base = [&](int g) { return co0 + (g >> 2) * 32 + 8 * (g & 3); };  // wave-uniform first channel
         auto load_group = [&](auto gc, float (&dst)[GE]) {
@@ -420,7 +440,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 for (int j = 0; j < 4; ++j) {
                     // clamp the row so padded channel rows still read inside the tensor
                     const int cs = (FULL || cs0 + j + 4 < a.cout) ? cs0 + j : 0;
-                    const float* const p1 = a.res1 + size_t(cs) * HW;
+                    const float* const p1 = t_res1 + size_t(cs) * HW;
 #pragma unroll
                     for (int n = 0; n < C::NT; ++n) dst[j * C::NT + n] = p1[o_r1[n]];
                 }
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int cs = (FULL || cs0 + j + 4 < a.cout) ? cs0 + j : 0;
-                        const float* const p2 = a.res2 + size_t(cs) * HW;
+                        const float* const p2 = t_res2 + size_t(cs) * HW;
 #pragma unroll
                         for (int n = 0; n < C::NT; ++n) dst[j * C::NT + n] += p2[o_r2[n]];
                     }
@@ -440,6 +460,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             constexpr int g = decltype(gc)::value;
             constexpr int m = g >> 2, rg = g & 3;
             if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, resv[(g + 1) & 1]);
+            // keep the next group's loads HERE: the scheduler otherwise sinks them to their first use and
+            // every group pays a full memory round trip
+            __builtin_amdgcn_sched_barrier(0);
             const int cs0 = group_base(g);
             // bias / post-BN parameters of this lane's four channels: ONE 16-byte load each (the
             // vectors are padded to cout_pad, so rows beyond cout read zeros, never out of bounds)
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             if (a.out_raw) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float* const p = a.out_raw + size_t(cs0 + j) * HW;
+                    float* const p = t_raw + size_t(cs0 + j) * HW;
 #pragma unroll
                     for (int n = 0; n < C::NT; ++n)
                         if (okc[j] && lane_ok[n]) p[o_raw[n]] = vals[j * C::NT + n];
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 if (a.pool_out) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float* const p = a.pool_out + size_t(cs0 + j) * (HW / 4);
+                        float* const p = t_pool + size_t(cs0 + j) * (HW / 4);
 #pragma unroll
                         for (int q = 0; q < C::NT / 2; ++q) {
                             const float v2 = fmaxf(vals[j * C::NT + 2 * q], vals[j * C::NT + 2 * q + 1]);
@@ -495,7 +518,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 if (a.up_out != 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float* const p = a.out + size_t(cs0 + j) * HW * (a.up_out ? 4 : 1);
+                        float* const p = t_out + size_t(cs0 + j) * HW * (a.up_out ? 4 : 1);
 #pragma unroll
                         for (int n = 0; n < C::NT; ++n)
                             if (okc[j] && lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
@@ -506,8 +529,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                     for (int j = 0; j < 4; ++j) {
                         // the row's skip loads first, then its 2x2 scatter
                         const int cs = okc[j] ? cs0 + j : 0;
-                        const float* const ps = a.skip + size_t(cs) * HW * 4;
-                        float* const p = a.out + size_t(cs0 + j) * HW * 4;
+                        const float* const ps = t_skip + size_t(cs) * HW * 4;
+                        float* const p = t_out + size_t(cs0 + j) * HW * 4;
                         float2 s0[C::NT], s1[C::NT];
 #pragma unroll
                         for (int n = 0; n < C::NT; ++n) {
@@ -527,10 +550,138 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             }
         });
     };
-    if (co0 + C::COUT_T <= a.cout)
+    // Branch-free epilogues for the layer kinds that carry the time (full channel tiles, plain
+    // NCHW output).  The general epilogue above tests its feature flags per group; at every join
+    // of such a branch the compiler has to assume the worst about outstanding memory operations
+    // and drains the pipeline (s_waitcnt vmcnt(0)) - which serialises "load residual, add, store"
+    // into one memory round trip per group (measured: 74k of a c128 tile's 1.3M cycles).  With
+    // the flags as template parameters every load and store is unconditional, the waits are exact
+    // and the residual / parameter prefetch really runs ahead.
+    //   RAW: also store the pre-residual value (input of the block's next conv)
+    //   RES: add the residual slice        PAR: 0 none, 1 bias, 2 bias + post-BatchNorm + ReLU
+    //   POOL: also store the 2x2 max-pooled value
+    auto epilogue_fast = [&](auto raw_c, auto res_c, auto par_c, auto pool_c) __attribute__((always_inline)) {
+        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value, POOL = decltype(pool_c)::value;
+        constexpr int PAR = decltype(par_c)::value;
+        // residual prefetch distance in groups (measured: 3 and 5 perform alike, 6 spills on the
+        // 128-accumulator tiles)
+        constexpr int PF_WANT = (GE <= 8) ? 3 : 1;
+        constexpr int PF = RES ? (PF_WANT < NG ? PF_WANT : NG) : 0;
+        constexpr int RING = PF + 1;
+        float resv[RING][GE];
+        f32x4 bias_r[2], ps_r[2], pt_r[2];
+        auto chan0 = [&](int g) { return co0 + (g >> 2) * 32 + 8 * (g & 3); };  // wave-uniform first channel
+        auto ld_res = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (RES) {
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const float* const p1 = a.res1 + size_t(chan0(g) + j) * HW;
+                    static_for<0, C::NT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        resv[g % RING][j * C::NT + n] = p1[o_r1[n]];
+                    });
+                });
+            }
+        };
+        auto ld_par = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (PAR >= 1) bias_r[g & 1] = *reinterpret_cast<const f32x4*>(a.bias + chan0(g) + 4 * half);
+            if constexpr (PAR == 2) {
+                ps_r[g & 1] = *reinterpret_cast<const f32x4*>(a.post_scale + chan0(g) + 4 * half);
+                pt_r[g & 1] = *reinterpret_cast<const f32x4*>(a.post_shift + chan0(g) + 4 * half);
+            }
+        };
+        static_for<0, (PF < NG ? PF : NG)>([&](auto gc) { ld_res(gc); });
+        ld_par(std::integral_constant<int, 0>{});
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int m = g >> 2, rg = g & 3;
+            if constexpr (g + PF < NG) ld_res(std::integral_constant<int, g + PF>{});
+            if constexpr (g + 1 < NG) ld_par(std::integral_constant<int, g + 1>{});
+            __builtin_amdgcn_sched_barrier(0);  // the prefetches stay ahead of this group's work
+            const int cs0 = chan0(g);
+            float vals[GE];
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<0, C::NT>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    float v = acc[m][n][4 * rg + j];
+                    if constexpr (PAR >= 1) v += bias_r[g & 1][j];
+                    if constexpr (PAR == 2) v = fmaxf(fmaf(v, ps_r[g & 1][j], pt_r[g & 1][j]), 0.f);
+                    vals[j * C::NT + n] = v;
+                });
+            });
+            if constexpr (RAW) {
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    float* const p = a.out_raw + size_t(cs0 + j) * HW;
+                    static_for<0, C::NT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        if (lane_ok[n]) p[o_raw[n]] = vals[j * C::NT + n];
+                    });
+                });
+            }
+            if constexpr (RES) {
+                static_for<0, GE>([&](auto ec) { vals[decltype(ec)::value] += resv[g % RING][decltype(ec)::value]; });
+            }
+            if constexpr (POOL && CAN_POOL) {
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    float* const p = a.pool_out + size_t(cs0 + j) * (HW / 4);
+                    static_for<0, C::NT / 2>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        const float v2 = fmaxf(vals[j * C::NT + 2 * q], vals[j * C::NT + 2 * q + 1]);
+                        const int vi = __float_as_int(v2);
+                        const float other = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xf, 0xf, false));  // lane ^ 1
+                        if ((l31 & 1) == 0) p[o_pool[q]] = fmaxf(v2, other);
+                    });
+                });
+            }
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                float* const p = a.out + size_t(cs0 + j) * HW;
+                static_for<0, C::NT>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if (lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
+                });
+            });
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P2 = std::integral_constant<int, 2>;
+    const bool full_tile = co0 + C::COUT_T <= a.cout;
+    const bool fast_ok = full_tile && !C::SPLITK && a.out && !a.up_out && !a.res2 && !a.skip && (CAN_POOL || !a.pool_out);
+    const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr, has_pool = a.pool_out != nullptr;
+    const int par = a.post_scale ? (a.bias ? 2 : -1) : (a.bias ? 1 : 0);
+    if (fast_ok && has_raw && has_res && par == 0 && !has_pool)
+        epilogue_fast(T_{}, T_{}, P0{}, F_{});  // block conv1 / conv2
+    else if (fast_ok && !has_raw && has_res && par == 0 && !has_pool)
+        epilogue_fast(F_{}, T_{}, P0{}, F_{});  // block conv3
+    else if (fast_ok && has_raw && has_res && par == 0 && has_pool)
+        epilogue_fast(T_{}, T_{}, P0{}, T_{});  // ... of a block that is pooled next
+    else if (fast_ok && !has_raw && has_res && par == 0 && has_pool)
+        epilogue_fast(F_{}, T_{}, P0{}, T_{});
+    else if (fast_ok && !has_raw && !has_res && par == 2 && !has_pool)
+        epilogue_fast(F_{}, F_{}, P2{}, F_{});  // conv1, conv5, conv9
+    else if (fast_ok && !has_raw && !has_res && par == 0 && !has_pool)
+        epilogue_fast(F_{}, F_{}, P0{}, F_{});  // 1x1 resample
+    else if (full_tile)
         epilogue(std::true_type{});
     else
         epilogue(std::false_type{});
+#if defined(MVLM_CONV_TIMING)
+    if (a.timing && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);  // the epilogue's stores have left the wave
+        const long long t_end = clock64();
+        atomicAdd(a.timing + 0, (unsigned long long)(t_loop - t_start));
+        atomicAdd(a.timing + 1, (unsigned long long)(t_epi - t_loop));
+        atomicAdd(a.timing + 2, (unsigned long long)(t_end - t_epi));
+        atomicAdd(a.timing + 3, 1ull);
+    }
+#endif
 
     // ---- the 16-row strip: plain conv + bias layers only (conv6, conv10, conv11; checked on the host) ----
     int pix16[C::NT16];            // output pixel index of column group j (full resolution for up_out == 2)
@@ -664,7 +815,11 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
 // id, name, instantiation.  W >= 32 uses row-segment tiles; smaller levels fold rows /
 // images into the 32-pixel MFMA column.
 template <class C>
-int launch_variant(mvlm_ctx* ctx, const ConvArgs& a) {
+int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in) {
+    ConvArgs a = a_in;
+#if defined(MVLM_CONV_TIMING)  // diagnostic build: the tool passes its counter buffer through the environment
+    if (const char* e = getenv("MVLM_CONV_TIMING_BUF")) a.timing = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     const int tiles_x = a.W / C::TW, tiles_y = a.H / C::TRI;
     const int tiles_b = (a.B + C::NIMG - 1) / C::NIMG;
     const int cout_tiles = a.cout_pad / C::COUT_T;
