@@ -82,7 +82,7 @@ struct StageRegs {
 // Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
 // padding elements read element 0 and are zeroed at write time): a branch around a load makes
 // the compiler wait for each one separately.
-template <class C, int T>
+template <class C, int T, bool BN_FROM_GLOBAL = false>
 __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
                                            const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
                                            StageRegs<C>& r, float* st_dst) {
@@ -94,8 +94,13 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
         r.xv[T] = base[ok ? goff[T] : 0u];
         if (a.pre_scale != nullptr) {  // this element's BatchNorm scale / shift from the LDS copy
             const int cc = c < a.cin_pad ? c : 0;
-            r.bn_s[T] = sbn[cc];
-            r.bn_t[T] = sbn[C::BN_MAXC + cc];
+            if constexpr (BN_FROM_GLOBAL) {  // first chunk: the LDS copy is still being filled
+                r.bn_s[T] = a.pre_scale[cc];
+                r.bn_t[T] = a.pre_shift[cc];
+            } else {
+                r.bn_s[T] = sbn[cc];
+                r.bn_t[T] = sbn[C::BN_MAXC + cc];
+            }
         }
     } else {
         constexpr int I = T - C::X_ITERS;
@@ -302,18 +307,19 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         acc16[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // the consumer-side BatchNorm (scale, shift per input channel) is read from LDS
+    // The consumer-side BatchNorm (scale, shift per input channel) is read from an LDS copy.  The first
+    // chunk takes its parameters straight from global memory, so the table fill, the first input tile
+    // and the first weight slice are ONE memory round trip, closed by the barrier below.
     float* sbn = smem + 2 * C::STAGE;
+    StageRegs<C> regs;
+    constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true>(a, 0, tid, HWin, sbn, goff, woff_g, regs, smem); });
     if (a.pre_scale != nullptr) {
         for (int i = tid; i < a.cin_pad; i += 256) {
             sbn[i] = a.pre_scale[i];
             sbn[C::BN_MAXC + i] = a.pre_shift[i];
         }
-        __syncthreads();
     }
-    StageRegs<C> regs;
-    constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
-    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value>(a, 0, tid, HWin, sbn, goff, woff_g, regs, smem); });
     static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, 0, tid, smem, goff, regs); });
     __syncthreads();
 
