@@ -567,7 +567,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     //   RES: add the residual slice        PAR: 0 none, 1 bias, 2 bias + post-BatchNorm + ReLU
     //   POOL: also store the 2x2 max-pooled value
     auto epilogue_fast = [&](auto raw_c, auto res_c, auto par_c, auto pool_c) __attribute__((always_inline)) {
-        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value, POOL = decltype(pool_c)::value;
+        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value;
+        constexpr bool POOL = decltype(pool_c)::value != 0, FULL_OUT = decltype(pool_c)::value != 2;  // 2: pooled tensor only
         constexpr int PAR = decltype(par_c)::value;
         // residual prefetch distance in groups (measured: 3 and 5 perform alike, 6 spills on the
         // 128-accumulator tiles)
@@ -644,14 +645,16 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                     });
                 });
             }
-            static_for<0, 4>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                float* const p = a.out + size_t(cs0 + j) * HW;
-                static_for<0, C::NT>([&](auto nc) {
-                    constexpr int n = decltype(nc)::value;
-                    if (lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
+            if constexpr (FULL_OUT) {
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    float* const p = a.out + size_t(cs0 + j) * HW;
+                    static_for<0, C::NT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        if (lane_ok[n]) p[o_out[n]] = vals[j * C::NT + n];
+                    });
                 });
-            });
+            }
         });
     };
     using T_ = std::true_type;
@@ -659,21 +662,29 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     using P0 = std::integral_constant<int, 0>;
     using P2 = std::integral_constant<int, 2>;
     const bool full_tile = co0 + C::COUT_T <= a.cout;
-    const bool fast_ok = full_tile && !C::SPLITK && a.out && !a.up_out && !a.res2 && !a.skip && (CAN_POOL || !a.pool_out);
     const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr, has_pool = a.pool_out != nullptr;
+    const bool fast_ok = full_tile && !C::SPLITK && (a.out || has_pool) && !a.up_out && !a.res2 && !a.skip && (CAN_POOL || !has_pool);
     const int par = a.post_scale ? (a.bias ? 2 : -1) : (a.bias ? 1 : 0);
-    if (fast_ok && has_raw && has_res && par == 0 && !has_pool)
-        epilogue_fast(T_{}, T_{}, P0{}, F_{});  // block conv1 / conv2
-    else if (fast_ok && !has_raw && has_res && par == 0 && !has_pool)
-        epilogue_fast(F_{}, T_{}, P0{}, F_{});  // block conv3
-    else if (fast_ok && has_raw && has_res && par == 0 && has_pool)
-        epilogue_fast(T_{}, T_{}, P0{}, T_{});  // ... of a block that is pooled next
-    else if (fast_ok && !has_raw && has_res && par == 0 && has_pool)
-        epilogue_fast(F_{}, T_{}, P0{}, T_{});
-    else if (fast_ok && !has_raw && !has_res && par == 2 && !has_pool)
-        epilogue_fast(F_{}, F_{}, P2{}, F_{});  // conv1, conv5, conv9
-    else if (fast_ok && !has_raw && !has_res && par == 0 && !has_pool)
-        epilogue_fast(F_{}, F_{}, P0{}, F_{});  // 1x1 resample
+    const int pool_mode = has_pool ? (a.out ? 1 : 2) : 0;
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    if (fast_ok && has_raw && has_res && par == 0 && pool_mode == 0)
+        epilogue_fast(T_{}, T_{}, P0{}, M0{});  // block conv1 / conv2
+    else if (fast_ok && !has_raw && has_res && par == 0 && pool_mode == 0)
+        epilogue_fast(F_{}, T_{}, P0{}, M0{});  // block conv3
+    else if (fast_ok && has_raw && has_res && par == 0 && pool_mode == 1)
+        epilogue_fast(T_{}, T_{}, P0{}, M1{});  // ... of a block that is pooled next
+    else if (fast_ok && !has_raw && has_res && par == 0 && pool_mode == 1)
+        epilogue_fast(F_{}, T_{}, P0{}, M1{});
+    else if (fast_ok && has_raw && has_res && par == 0 && pool_mode == 2)
+        epilogue_fast(T_{}, T_{}, P0{}, M2{});  // ... whose full-resolution output nobody reads (stem)
+    else if (fast_ok && !has_raw && has_res && par == 0 && pool_mode == 2)
+        epilogue_fast(F_{}, T_{}, P0{}, M2{});
+    else if (fast_ok && !has_raw && !has_res && par == 2 && pool_mode == 0)
+        epilogue_fast(F_{}, F_{}, P2{}, M0{});  // conv1, conv5, conv9
+    else if (fast_ok && !has_raw && !has_res && par == 0 && pool_mode == 0)
+        epilogue_fast(F_{}, F_{}, P0{}, M0{});  // 1x1 resample
     else if (full_tile)
         epilogue(std::true_type{});
     else
