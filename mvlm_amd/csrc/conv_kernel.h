@@ -48,6 +48,8 @@ struct Cfg {
     // COUT_T = 32*MT + 16: the last 16 output channels run on v_mfma_f32_16x16x4_f32 (same FLOP rate,
     // half the rows), so a 73-landmark layer pads to 80 rows instead of 96
     static constexpr bool TAIL16 = COUT_T % 32 == 16;
+    // the fused argmax serves the last layer only (73 / 84 landmarks -> 80 / 96-row tiles of 8x32 pixels)
+    static constexpr bool HAS_AMAX = NIMG == 1 && TW == 32 && TRI == 8 && KS != 1 && (COUT_T == 80 || COUT_T == 96);
     static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
     static constexpr int NT16 = TAIL16 ? 2 * NT : 1;  // 16-pixel column groups of a wave
     static constexpr int KSTEPS = TAPS * CKW / 2;
@@ -859,13 +861,13 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in) {
     if (!attr_set) {
         MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
-        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS != 1)
+        if constexpr (C::HAS_AMAX)
             MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
         attr_set = true;
     }
     if (a.amax_val) {
-        if constexpr (C::NIMG == 1 && C::TW == 32 && C::TRI == 8 && C::KS != 1) {
+        if constexpr (C::HAS_AMAX) {
             hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream,
                                a, tiles_x, tiles_y, cout_tiles);
         } else {

@@ -6,26 +6,31 @@
 #define MVLM_CONV_VARIANTS_G0(X) \
     X(0, "conv3x3_c128_t8x32", Cfg<128, 32, 8, 1, 3, 4>)
 #define MVLM_CONV_VARIANTS_G1(X) \
-    X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3, 4>) \
-    X(11, "conv2x2_c96_t8x32", Cfg<96, 32, 8, 1, 2, 4>)
+    X(1, "conv3x3_c96_t8x32", Cfg<96, 32, 8, 1, 3, 4>)
 #define MVLM_CONV_VARIANTS_G2(X) \
-    X(16, "conv3x3_c80_t8x32", Cfg<80, 32, 8, 1, 3, 4>) \
-    X(17, "conv2x2_c80_t8x32", Cfg<80, 32, 8, 1, 2, 4>)
+    X(11, "conv2x2_c96_t8x32", Cfg<96, 32, 8, 1, 2, 4>)
 #define MVLM_CONV_VARIANTS_G3(X) \
-    X(10, "conv3x3_c64_t8x32", Cfg<64, 32, 8, 1, 3, 4>) \
+    X(16, "conv3x3_c80_t8x32", Cfg<80, 32, 8, 1, 3, 4>)
+#define MVLM_CONV_VARIANTS_G4(X) \
+    X(17, "conv2x2_c80_t8x32", Cfg<80, 32, 8, 1, 2, 4>)
+#define MVLM_CONV_VARIANTS_G5(X) \
+    X(10, "conv3x3_c64_t8x32", Cfg<64, 32, 8, 1, 3, 4>)
+#define MVLM_CONV_VARIANTS_G6(X) \
     X(9, "conv3x3_c64_t4x32", Cfg<64, 32, 4, 1, 3, 4>) \
     X(8, "conv3x3_c128_t4x32", Cfg<128, 32, 4, 1, 3, 4>)
-#define MVLM_CONV_VARIANTS_G4(X) \
+#define MVLM_CONV_VARIANTS_G7(X) \
     X(3, "conv3x3_c32_t16x32", Cfg<32, 32, 16, 1, 3, 4>) \
-    X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 8>) \
+    X(4, "conv1x1_c128_t8x32", Cfg<128, 32, 8, 1, 1, 8>)
+#define MVLM_CONV_VARIANTS_G8(X) \
     X(5, "conv3x3_c32_t8x16", Cfg<32, 16, 8, 1, 3, 16>) \
     X(6, "conv3x3_c32_t8x8x2", Cfg<32, 8, 8, 2, 3, 16>) \
     X(7, "conv3x3_c32_t4x4x8", Cfg<32, 4, 4, 8, 3, 16>)
-#define MVLM_CONV_VARIANTS_G5(X) \
+#define MVLM_CONV_VARIANTS_G9(X) \
     X(12, "conv3x3_sk_t2x16", Cfg<32, 16, 2, 1, 3, 32, true>) \
     X(13, "conv3x3_sk_t4x8", Cfg<32, 8, 4, 1, 3, 32, true>) \
     X(14, "conv3x3_sk_t4x4x2", Cfg<32, 4, 4, 2, 3, 32, true>) \
     X(15, "conv3x3_sk_t1x32", Cfg<32, 32, 1, 1, 3, 32, true>)
-#define MVLM_CONV_VARIANTS(X) MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X)
-#define MVLM_CONV_N_GROUPS 6
+#define MVLM_CONV_VARIANTS(X) \
+    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X)
+#define MVLM_CONV_N_GROUPS 10
 #endif
