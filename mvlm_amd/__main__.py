@@ -9,10 +9,16 @@ predictor this build ships are looped ("bu3dfe", "dtu3d"); the viewer flags of t
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 from pathlib import Path
 
 import numpy as np
+
+
+def shard_files(files, rank: int, world: int):
+    """Round-robin share of ``files`` for ``rank`` of ``world`` processes (order preserved)."""
+    return [f for i, f in enumerate(files) if i % world == rank]
 
 
 def main(argv=None) -> int:
@@ -45,6 +51,14 @@ def main(argv=None) -> int:
             print("Given folder does not contain any .obj files.")
             return 1
     path_to_out.mkdir(parents=True, exist_ok=True)
+    # one process per GPU (python -m torch.distributed.run --nproc-per-node N -m mvlm_amd -p folder/): scans are
+    # independent, so rank r simply takes every N-th file on its own GPU - no collective, N times the folder rate
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        obj_files = shard_files(obj_files, rank, world)
+        if args.device == 0:
+            args.device = int(os.environ.get("LOCAL_RANK", "0"))
+        print(f"[rank {rank}/{world}] {len(obj_files)} scans on GPU {args.device}")
 
     from . import pipeline
 

@@ -295,3 +295,12 @@ def test_prealign_round_trip():
     back = landmarks_to_original_space(out.verts.astype(np.float64), m)
     np.testing.assert_allclose(back, verts, atol=1e-4)
     assert np.array_equal(prealign_matrix(verts, dict(scale=1)), np.eye(4))
+
+
+def test_cli_shards_scans_across_ranks():
+    from mvlm_amd.__main__ import shard_files
+
+    files = [f"s{i}.obj" for i in range(10)]
+    parts = [shard_files(files, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == sorted(files) and parts[0] == ["s0.obj", "s4.obj", "s8.obj"]
+    assert shard_files(files, 0, 1) == files
