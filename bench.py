@@ -4,20 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one batch of synthetic input: render all views of
-a ~100k-triangle textured face mesh, run the landmark network on every view, take the heatmap
-maxima, build the rays, fuse them per landmark and snap the result to the surface.  The mesh,
-its texture and the weights are resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over one mesh: render all views of a ~100k-triangle textured
+face mesh, run the landmark network on every view, take the heatmap maxima, build the rays, fuse
+them per landmark and snap the result to the surface.  The mesh, its texture and the weights are
+resident in HBM before the timed region starts.
 
-Workload (BASELINE.json configs[1]): DTU3D-RGB (73 landmarks, 3 input channels), 64 views at
-256x256 per GPU.  With N GPUs the mesh gets 64*N views sharded 64 per rank (weak scaling) with
-one all-gather of the per-view maxima (RCCL) before fusion.
+Default workload = the configuration BASELINE.json's metric is quoted on: configs[2],
+BU_3DFE-RGB+depth.json (84 landmarks, 4 input channels), 96 views at 256x256 of one mesh.
+With N GPUs the SAME 96 views are sharded 96/N per rank (strong scaling - BASELINE's
+"96 views sharded 12/GPU across 8x MI355X") with one all-gather of the per-view maxima (RCCL)
+before fusion; `--scaling weak` keeps 96 views per GPU instead.  Other BASELINE configurations:
+`--config dtu3d-rgb-64 | bu3dfe-depth-8 | dtu3d-geomdepth-96 | mediapipe-478x128`.
 
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -30,6 +34,18 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; ~6.3 TB/s is achievable)
+
+# BASELINE.json configs[i] -> what the bench builds.  `views` is the mesh's view count the config names.
+CONFIGS = {
+    "bu3dfe-depth-8": dict(index=0, json="BU_3DFE-depth.json", dataset="BU_3DFE", mode="depth", views=8),
+    "dtu3d-rgb-64": dict(index=1, json="DTU3D-RGB.json", dataset="DTU3D", mode="RGB", views=64),
+    "bu3dfe-rgbd-96": dict(index=2, json="BU_3DFE-RGB+depth.json", dataset="BU_3DFE", mode="RGB+depth", views=96),
+    "dtu3d-geomdepth-96": dict(index=3, json="DTU3D-geometry+depth.json", dataset="DTU3D", mode="geometry+depth", views=96),
+    # config 5: the 2-D detector is third-party (out of scope); render + dense fusion with synthetic 2-D landmarks
+    "mediapipe-478x128": dict(index=4, json=None, dataset=None, mode=None, views=128, landmarks=478),
+}
+DEFAULT_CONFIG = "bu3dfe-rgbd-96"
 
 
 def log(*a):
@@ -37,7 +53,8 @@ def log(*a):
 
 
 def host_cores() -> int:
-    """CPU threads this process may really use: affinity mask capped by the cgroup quota."""
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota
+    (MVLM_BENCH_CPU_THREADS lowers it; there is no default cap)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
@@ -45,12 +62,14 @@ def host_cores() -> int:
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:  # noqa: BLE001
         pass
-    return max(1, min(n, int(os.environ.get("MVLM_BENCH_CPU_THREADS", "16"))))
+    if os.environ.get("MVLM_BENCH_CPU_THREADS"):
+        n = min(n, int(os.environ["MVLM_BENCH_CPU_THREADS"]))
+    return max(1, n)
 
 
-def cpu_baseline(mesh, poses, sd, chan_sel, n_sample: int):
+def cpu_baseline(mesh, poses, sd, chan_sel, n_sample: int, n_workload: int):
     """Time the CPU oracle (a port of the reference path; the reference's own VTK renderer
-    cannot run here) on a bounded sample of the same workload, on this box's host cores."""
+    cannot run here) on a bounded sample of the same workload, on all of this box's host cores."""
     import torch
 
     from oracle import pipeline as opipe
@@ -65,9 +84,9 @@ def cpu_baseline(mesh, poses, sd, chan_sel, n_sample: int):
     opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, sub, sd, chan_sel, batch_size=2, timings=timings)
     dt = time.time() - t0
     return {"value": round(n_sample / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} of the workload's views through the CPU oracle (software rasteriser + "
-                      f"torch-CPU fp32 network, batch 2 like the reference, + numpy fusion), {dt:.1f} s; stages "
-                      + ", ".join(f"{k} {v:.2f}s" for k, v in timings.items())}
+            "sample": f"{n_sample} of the workload's {n_workload} views through the CPU oracle (software rasteriser + "
+                      f"torch-CPU fp32 network, batch 2 like the reference, + numpy fusion) on all {cores} host "
+                      f"threads, {dt:.1f} s; stages " + ", ".join(f"{k} {v:.2f}s" for k, v in timings.items())}
 
 
 def ingest_figures(pipe, n_views: int, n_files: int = 12):
@@ -111,16 +130,64 @@ def ingest_figures(pipe, n_views: int, n_files: int = 12):
                     "with the next scan's ingest on a reader thread"}
 
 
+def synthetic_landmark_predictor(mesh, poses, n_landmarks: int, device):
+    """BASELINE configs[4]: ground-truth surface points projected into every view + N(0, 0.5 px)
+    noise + 10 % uniform outliers, score U(0,1), in the MediaPipe predictor's output format
+    (mediapipepredictor.py:46-48) - resident on the GPU, handed over by a PrecomputedPredictor."""
+    import torch
+
+    from mvlm_amd.prediction import PrecomputedPredictor
+    from mvlm_amd.utils.render3d import view_rotations
+
+    rs = np.random.RandomState(478)
+    pts = mesh.verts[rs.choice(mesh.n_verts, n_landmarks, replace=False)].astype(np.float64)
+    rot = view_rotations(poses).reshape(-1, 3, 3)
+    n = rot.shape[0]
+    lms = np.empty((n_landmarks, n, 3), np.float32)
+    for v in range(n):
+        q = pts @ rot[v].T
+        lms[:, v, 1] = (q[:, 0] + 150) / 300 * 256 + rs.normal(0, 0.5, n_landmarks)
+        lms[:, v, 0] = 255 - (q[:, 1] + 150) / 300 * 256 + rs.normal(0, 0.5, n_landmarks)
+        lms[:, v, 2] = rs.rand(n_landmarks)
+    bad = rs.rand(n_landmarks, n) < 0.1
+    lms[bad, 0] = rs.uniform(0, 255, bad.sum())
+    lms[bad, 1] = rs.uniform(0, 255, bad.sum())
+    lms_dev = torch.from_numpy(lms).to(device)
+    state = {"lo": 0}
+
+    def device_fn(images):
+        lo = state["lo"]
+        return lms_dev[:, lo:lo + int(images.shape[0])].contiguous()
+
+    return PrecomputedPredictor(n_landmarks, device_fn=device_fn), state, pts
+
+
+def committed_traffic(workload_key: str, kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC pass of THIS workload
+    (profiles/rNN_traffic.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the process; a profile of another
+    workload says nothing about this one, so anything but an exact workload match gives null."""
+    for f in sorted((REPO / "profiles").glob("r*_traffic.json"), reverse=True):
+        try:
+            rec = json.loads(f.read_text())
+        except Exception:  # noqa: BLE001
+            continue
+        if rec.get("workload") == workload_key and kernel in rec.get("kernels", {}):
+            return round(rec["kernels"][kernel]["hbm_bytes_per_launch"]), f.name
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--views-per-gpu", type=int, default=64)
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the config's view count sharded over the ranks (BASELINE), weak = that many per rank")
+    ap.add_argument("--views-total", type=int, default=0, help="override the config's view count")
     ap.add_argument("--device-batch", type=int, default=128)
-    ap.add_argument("--cpu-views", type=int, default=48, help="views in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--dataset", default="DTU3D")
-    ap.add_argument("--image-mode", default="RGB")
+    ap.add_argument("--cpu-views", type=int, default=-1, help="views in the CPU-baseline sample (-1 = the whole workload, at most 96; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +203,7 @@ def main():
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
 
@@ -143,20 +211,36 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = f"{dist.get_backend()} world_size {dist.get_world_size()}"
 
     from mvlm_amd import arch, config, parallel, weights
     from mvlm_amd.utils.synthetic import face_like_mesh
 
-    cfg = config.load_config(config.default_config(args.dataset, args.image_mode, n_views=args.views_per_gpu * world))
-    pipe = cfg.build_pipeline(weights="synthetic:0", device=local_rank, shard_views=world > 1, verbose=False,
-                              device_batch=args.device_batch)
-    nl, c = pipe.get_lm_count(), cfg.in_channels
+    spec = CONFIGS[args.config]
+    views_cfg = args.views_total or spec["views"]
+    n_total = views_cfg * world if args.scaling == "weak" else views_cfg
+    fusion_only = spec["dataset"] is None
     mesh = face_like_mesh(224, 2048, seed=0)  # 99 458 triangles, 2048^2 texture
-    n_total = args.views_per_gpu * world
+
+    if fusion_only:
+        from mvlm_amd import pipeline
+
+        pipe = pipeline.Pipeline(n_views=n_total, device=local_rank, shard_views=world > 1, verbose=False)
+        nl, c, cfg = spec["landmarks"], 0, None
+    else:
+        cfg = config.load_config(config.default_config(spec["dataset"], spec["mode"], n_views=n_total))
+        pipe = cfg.build_pipeline(weights="synthetic:0", device=local_rank, shard_views=world > 1, verbose=False,
+                                  device_batch=args.device_batch)
+        nl, c = pipe.get_lm_count(), cfg.in_channels
     pipe.renderer_3d.n_views = n_total
     np.random.seed(0)
     poses = pipe.renderer_3d.generate_3d_transformations() if rank == 0 else None
-    poses = parallel.broadcast_array(poses)
+    poses = parallel.broadcast_array(poses, (n_total, 6), device=local_rank)
+    lo, hi = parallel.shard_range(n_total, rank, world) if world > 1 else (0, n_total)
+    if fusion_only:
+        pred, pred_state, _ = synthetic_landmark_predictor(mesh, poses, nl, torch.device("cuda", local_rank))
+        pred_state["lo"] = lo
+        pipe.predictor_2d = pred
 
     def barrier():
         if world > 1:
@@ -167,37 +251,45 @@ def main():
         np.random.seed(1)
         return pipe.predict_mesh_device(mesh, poses)
 
-    ctx = pipe.predictor_2d.ctx
-    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+    cnn_ctx = None if fusion_only else pipe.predictor_2d.ctx
+    r_ctx = pipe.renderer_3d.ctx
+    for _ in range(args.warmup):
         step()
     # per-kernel HIP events on the launch stream, live over the timed region
-    ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 1)
-    prof = {}
-    per_slot = {}
+    if cnn_ctx is not None:
+        cnn_ctx.lib.mvlm_cnn_set_profiling(cnn_ctx.handle, 1)
+    r_ctx.lib.mvlm_render_set_profiling(r_ctx.handle, 1)
+    prof, per_slot = {}, {}
+    render_ms, render_calls = 0.0, 0
+    cap = 1024
+    slot, var = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    fl, ms = (C.c_double * cap)(), (C.c_float * cap)()
+    rv, rverts, rtris, rms = (C.c_int32 * 64)(), (C.c_int32 * 64)(), (C.c_int32 * 64)(), (C.c_float * 64)()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lm, err = step()
-        # collect this step's per-conv records (event queries only, after the step's final sync)
-        import ctypes as C
-        cap = 1024
-        slot = (C.c_int32 * cap)()
-        var = (C.c_int32 * cap)()
-        fl = (C.c_double * cap)()
-        ms = (C.c_float * cap)()
-        n = ctx.lib.mvlm_cnn_get_profile(ctx.handle, slot, var, fl, ms, cap)
+        step()
+        # collect this step's records (event queries only, after the step's final sync)
+        if cnn_ctx is not None:
+            n = cnn_ctx.lib.mvlm_cnn_get_profile(cnn_ctx.handle, slot, var, fl, ms, cap)
+            for i in range(max(n, 0)):
+                p = prof.setdefault(var[i], [0.0, 0.0, 0])
+                p[0] += fl[i]
+                p[1] += ms[i]
+                p[2] += 1
+                q = per_slot.setdefault((slot[i], var[i]), [0.0, 0.0, 0])
+                q[0] += fl[i]
+                q[1] += ms[i]
+                q[2] += 1
+        n = r_ctx.lib.mvlm_render_get_profile(r_ctx.handle, rv, rverts, rtris, rms, 64)
         for i in range(max(n, 0)):
-            p = prof.setdefault(var[i], [0.0, 0.0, 0])
-            p[0] += fl[i]
-            p[1] += ms[i]
-            p[2] += 1
-            q = per_slot.setdefault((slot[i], var[i]), [0.0, 0.0, 0])
-            q[0] += fl[i]
-            q[1] += ms[i]
-            q[2] += 1
+            render_ms += rms[i]
+            render_calls += 1
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0)
+    if cnn_ctx is not None:
+        cnn_ctx.lib.mvlm_cnn_set_profiling(cnn_ctx.handle, 0)
+    r_ctx.lib.mvlm_render_set_profiling(r_ctx.handle, 0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -205,50 +297,65 @@ def main():
 
     if rank == 0:
         views_per_s = n_total * args.steps / elapsed
-        flops_view = arch.live_conv_flops_per_view(nl, c)
-        # dominant conv kernel variant by time
+        n_local = hi - lo
+        workload_key = f"{args.config}:{n_local}v/gpu"
+        flops_view = 0.0 if fusion_only else arch.live_conv_flops_per_view(nl, c)
+        # rasteriser: HBM-bound.  Algorithmic bytes per view: mesh read V*20 B + T*12 B,
+        # framebuffer write 256^2 * 16 B, one 3-byte texel per pixel at most
+        ras_bytes_view = mesh.n_verts * 20 + mesh.n_tris * 12 + 256 * 256 * 16 + 256 * 256 * 3
+        roof_r = None
+        if render_calls:
+            avg_ms = render_ms / render_calls
+            gbs = ras_bytes_view * n_local / (avg_ms * 1e-3) / 1e9
+            tr, src = committed_traffic(workload_key, "rasteriser")
+            roof_r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": tr, "kernel": "rasteriser (5 kernels of one mvlm_render)",
+                      "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes_per_view": ras_bytes_view,
+                      "views_per_launch": n_local}
         roof = None
         if prof:
-            dom = max(prof, key=lambda k: prof[k][1])
+            lib = cnn_ctx.lib
+            dom = max(prof, key=lambda k: prof[k][1])  # dominant conv kernel variant by time
             f, t_ms, cnt = prof[dom]
             achieved = f / (t_ms * 1e-3) / 1e12
             total_f = sum(p[0] for p in prof.values())
             total_ms = sum(p[1] for p in prof.values())
-            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC pass of the same
-            # command (FETCH_SIZE x2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); the
-            # counters cannot be read from inside this process, so the newest profiles/rNN_traffic.json is used
-            traffic = None
-            tfiles = sorted((REPO / "profiles").glob("r*_traffic.json"))
-            if tfiles:
-                rec = json.loads(tfiles[-1].read_text()).get(ctx.lib.mvlm_conv_variant_name(dom).decode())
-                if rec:
-                    traffic = round(rec["hbm_bytes_per_launch"])
+            name = lib.mvlm_conv_variant_name(dom).decode()
+            traffic, src = committed_traffic(workload_key, name)
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "kernel": ctx.lib.mvlm_conv_variant_name(dom).decode(),
-                    "kernel_avg_ms": round(t_ms / cnt, 4), "kernel_launches_per_step": cnt // args.steps,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                    "kernel": name, "kernel_avg_ms": round(t_ms / cnt, 4),
+                    "kernel_launches_per_step": cnt // args.steps,
                     "kernel_share_of_conv_time": round(t_ms / total_ms, 3),
                     "all_conv_kernels_tflops": round(total_f / (total_ms * 1e-3) / 1e12, 2),
+                    "all_conv_frac": round(total_f / (total_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "conv_ms_per_step": round(total_ms / args.steps, 3)}
             for k, (f, t_ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-                log(f"  {ctx.lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt // args.steps:3d}  "
+                log(f"  {lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt // args.steps:3d}  "
                     f"{t_ms / args.steps:8.3f} ms/step  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
-        if os.environ.get("MVLM_BENCH_PER_LAYER"):
-            names = [sl.name for sl in arch.conv_slots(nl, c)]
-            sizes = arch.conv_spatial_sizes()
-            for (sl, v), (f, t_ms, cnt) in sorted(per_slot.items()):
-                log(f"    slot {sl:3d} {names[sl]:22s} @{sizes[names[sl]]:3d} {ctx.lib.mvlm_conv_variant_name(v).decode():22s} "
-                    f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
+            if os.environ.get("MVLM_BENCH_PER_LAYER"):
+                names = [sl.name for sl in arch.conv_slots(nl, c)]
+                sizes = arch.conv_spatial_sizes()
+                for (sl, v), (f, t_ms, cnt) in sorted(per_slot.items()):
+                    log(f"    slot {sl:3d} {names[sl]:22s} @{sizes[names[sl]]:3d} {lib.mvlm_conv_variant_name(v).decode():22s} "
+                        f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
+        elif roof_r is not None:  # fusion-only workload: the rasteriser is the dominant kernel
+            roof, roof_r = roof_r, None
         log("stage seconds (last step):", {k: round(v, 5) for k, v in pipe.timings.items()})
         ingest = None
-        if world == 1 and not os.environ.get("MVLM_BENCH_NO_INGEST"):
+        if world == 1 and not fusion_only and not os.environ.get("MVLM_BENCH_NO_INGEST"):
             ingest = ingest_figures(pipe, n_total)
         cpu = None
-        if args.cpu_views > 0:
+        n_cpu = min(n_total, 96) if args.cpu_views < 0 else min(args.cpu_views, n_total)
+        if n_cpu > 0 and not fusion_only:
             sd = weights.synthetic_state_dict(nl, c, seed=0)
-            cpu = cpu_baseline(mesh, poses, sd, arch.CHANNEL_SELECT[cfg.image_channels], min(args.cpu_views, n_total))
+            cpu = cpu_baseline(mesh, poses, sd, arch.CHANNEL_SELECT[cfg.image_channels], n_cpu, n_total)
+        per_gpu = f"{n_local}" if world == 1 else f"{n_total // world}" + ("" if n_total % world == 0 else "+")
+        what = (f"configs[{spec['index']}] {spec['json']}" if spec["json"] else
+                f"configs[{spec['index']}] MediaPipe-shaped fusion stress (synthetic 2-D landmarks, no in-scope CNN)")
         out = {
-            "metric": "views/sec (render+CNN+fuse) per mesh, 256x256",
+            "metric": "views/sec (render+CNN+fuse) per mesh, 256x256x96 views" if views_cfg == 96 and not fusion_only
+                      else "views/sec (render+CNN+fuse) per mesh, 256x256",
             "value": round(views_per_s, 2),
             "unit": "views/s",
             "n_gpus": world,
@@ -256,22 +363,26 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not fusion_only else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.dataset}-{args.image_mode}.json, {args.views_per_gpu} views/GPU @ 256x256, "
-                                   f"{mesh.n_tris}-triangle textured synthetic face OBJ, {nl} landmarks, seeded "
-                                   "random weights",
-                       "views_total": n_total, "landmarks": nl, "in_channels": c, "triangles": mesh.n_tris,
+            "config": {"workload": f"{what}: {n_total} views @ 256x256 of one {mesh.n_tris}-triangle textured synthetic "
+                                   f"face OBJ, {nl} landmarks" + ("" if fusion_only else f", {c} input channels ({spec['mode']}), seeded random weights"),
+                       "name": args.config, "views_total": n_total, "views_per_gpu": per_gpu, "landmarks": nl,
+                       "in_channels": c, "triangles": mesh.n_tris,
                        "live_conv_gflop_per_view": round(flops_view / 1e9, 2),
-                       "parallelism": f"views sharded {args.views_per_gpu}/GPU x {world}, 1 all-gather of maxima"},
+                       "parallelism": f"views sharded {per_gpu}/GPU x {world} ({args.scaling} scaling; backend {backend}), "
+                                      "1 all-gather of maxima + 1 broadcast of RANSAC draws per mesh" if world > 1
+                                      else "1 GPU, no collective"},
             "roofline": roof,
+            "roofline_rasteriser": roof_r,
             "cpu_baseline": cpu,
             "with_ingest": ingest,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

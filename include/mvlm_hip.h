@@ -80,6 +80,11 @@ int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, in
  * three planes) for models trained on geometry renderings - the reference's renderer has no such
  * mode, parity unpinned. */
 int mvlm_set_render_shading(mvlm_ctx* ctx, int shading);
+/* HIP-event timing of the render kernels (bench.py's rasteriser roofline): while enabled every mvlm_render
+ * records one {n_views, n_verts, n_tris, ms}; get_profile waits for the stream, fills up to `cap` records,
+ * clears them and returns the count (-1 on failure). */
+int mvlm_render_set_profiling(mvlm_ctx* ctx, int enabled);
+int mvlm_render_get_profile(mvlm_ctx* ctx, int32_t* n_views, int32_t* n_verts, int32_t* n_tris, float* ms, int cap);
 /* mvlm_render only enqueues work; this waits for the stream and reports a deferred failure
  * (tile lists overflowed) of the renders since the last check */
 int mvlm_render_check(mvlm_ctx* ctx);

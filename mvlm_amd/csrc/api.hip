@@ -51,6 +51,8 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
     if (ctx->render_overflow_host) hipHostFree(ctx->render_overflow_host);
     for (auto e : ctx->cnn.event_pool)
         if (e) hipEventDestroy(e);
+    for (auto e : ctx->render_events)
+        if (e) hipEventDestroy(e);
     delete ctx;
 }
 

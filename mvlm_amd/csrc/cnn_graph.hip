@@ -208,8 +208,6 @@ struct Exec {
 
     // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
     bool pool_fusable(int slot, const Tensor& x, ConvArgs a, int S) {
-        static const bool off = getenv("MVLM_CNN_NO_POOL_FUSION") != nullptr;
-        if (off) return false;
         const int32_t* r = d(slot);
         a.cin = r[1];
         a.cout = r[2];

@@ -110,6 +110,11 @@ struct mvlm_mesh {
     size_t cap[4] = {0, 0, 0, 0};  // allocation sizes of verts / uvs / tris / tex (for the ctx's mesh pool)
 };
 
+struct RenderProfileRec {
+    int n_views, n_verts, n_tris;
+    hipEvent_t e0, e1;
+};
+
 struct mvlm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -118,8 +123,13 @@ struct mvlm_ctx {
     CnnState cnn;
     // grow-only internal scratch (raster bins, transformed vertices, small staging)
     std::map<std::string, std::pair<void*, size_t>> scratch;
+    unsigned long long conv_attr_mask = 0;  // conv variants whose launch attributes are set on this ctx's device
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render
+    bool render_profiling = false;        // mvlm_render_set_profiling: HIP events around each render's kernels
+    std::vector<RenderProfileRec> render_prof;
+    std::vector<hipEvent_t> render_events;
+    size_t render_event_cursor = 0;
     // device buffers of freed meshes, reused by the next upload: a folder of scans would otherwise pay
     // four hipMalloc + four (device-synchronising) hipFree per scan
     std::vector<std::pair<void*, size_t>> mesh_pool;

@@ -3,6 +3,6 @@
 #include "conv_variants.h"
 
 #define X(id, name, ...) \
-    int mvlm_conv_launch_##id(mvlm_ctx* ctx, const ConvArgs& a) { return launch_variant<__VA_ARGS__>(ctx, a); }
+    int mvlm_conv_launch_##id(mvlm_ctx* ctx, const ConvArgs& a) { return launch_variant<__VA_ARGS__>(ctx, a, id); }
 MVLM_CONV_VARIANTS_G8(X)
 #undef X

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
 // id, name, instantiation.  W >= 32 uses row-segment tiles; smaller levels fold rows /
 // images into the 32-pixel MFMA column.
 template <class C>
-int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in) {
+int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
     ConvArgs a = a_in;
 #if defined(MVLM_CONV_TIMING)  // diagnostic build: the tool passes its counter buffer through the environment
     if (const char* e = getenv("MVLM_CONV_TIMING_BUF")) a.timing = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
@@ -857,14 +857,15 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in) {
     }
     const long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
-    static bool attr_set = false;
-    if (!attr_set) {
+    // dynamic-LDS limit of this variant's kernels: set once per context, i.e. per device (hipFuncSetAttribute
+    // applies to the current device's copy of the function; the ctx mutex held by every entry point guards the mask)
+    if (!((ctx->conv_attr_mask >> variant_id) & 1ull)) {
         MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
         if constexpr (C::HAS_AMAX)
             MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
-        attr_set = true;
+        ctx->conv_attr_mask |= 1ull << variant_id;
     }
     if (a.amax_val) {
         if constexpr (C::HAS_AMAX) {

@@ -43,38 +43,32 @@ MVLM_CONV_VARIANTS(X)
 
 namespace {
 
+// level holds at most this many pixels in total -> latency-bound launch, split-K tiles
+constexpr long SPLITK_MAX_PIXELS = 8192;
+
 int pick_variant(const ConvArgs& a) {
-    // experiment knob: MVLM_CONV_TILE=small forces the 128-pixel tiles wherever they exist
-    static const bool force_small = [] {
-        const char* e = getenv("MVLM_CONV_TILE");
-        return e && std::string(e) == "small";
-    }();
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
     if (a.ksize == 2) return (a.W >= 32 && a.H % 8 == 0) ? (a.cout_pad == 96 ? 11 : a.cout_pad == 80 ? 17 : -1) : -1;
     if (a.cout_pad == 80) return (a.W >= 32 && a.H % 8 == 0) ? 16 : -1;  // 64 rows + one 16-row strip
-    if (a.W == 32 && a.cin_pad % 32 == 0 && !a.amax_val && !getenv("MVLM_CONV_NO_SPLITK") &&
-        long(a.B) * a.H * a.W <= (getenv("MVLM_CONV_SPLITK_PX") ? atol(getenv("MVLM_CONV_SPLITK_PX")) : 8192))
-        return 15;  // small batch at the 32x32 level: split-K tiles, see below
+    const long px = long(a.B) * a.H * a.W;
+    // tiny feature maps / small batches: few pixels in total -> the split-K tiles (32 pixels per
+    // workgroup, four waves share the K loop) shorten the serial chain; larger batches keep the
+    // 128-pixel tiles
+    const bool sk = a.cin_pad % 32 == 0 && px <= SPLITK_MAX_PIXELS && !a.amax_val;
+    if (a.W == 32 && sk) return 15;
     if (a.W >= 32) {
         // two workgroups fit a CU: below ~512 workgroups the 128-pixel tiles fill the chip better
-        const long px = long(a.B) * a.H * a.W;
         if (a.cout_pad % 128 == 0) {
             const long blocks = px / 256 * (a.cout_pad / 128);
-            return ((blocks < 512 || force_small) && !a.amax_val) ? 8 : 0;
+            return (blocks < 512 && !a.amax_val) ? 8 : 0;
         }
         if (a.cout_pad % 96 == 0) return 1;
         if (a.cout_pad % 64 == 0) {
             const long blocks = px / 256 * (a.cout_pad / 64);
-            return (blocks < 768 || force_small) ? 9 : 10;
+            return blocks < 768 ? 9 : 10;
         }
         return (a.H % 16 == 0) ? 3 : -1;
     }
-    // tiny feature maps: few pixels in total -> the split-K tiles (32 pixels per workgroup, four
-    // waves share the K loop) shorten the serial chain; larger batches keep the 128-pixel tiles
-    static const bool no_sk = getenv("MVLM_CONV_NO_SPLITK") != nullptr;
-    const long px_total = long(a.B) * a.H * a.W;
-    static const long sk_px = getenv("MVLM_CONV_SPLITK_PX") ? atol(getenv("MVLM_CONV_SPLITK_PX")) : 8192;
-    const bool sk = !no_sk && a.cin_pad % 32 == 0 && px_total <= sk_px && !a.amax_val;
     if (a.W == 16) return sk ? 12 : (a.cin_pad % 16 == 0 ? 5 : -1);
     if (a.W == 8) return sk ? 13 : (a.cin_pad % 16 == 0 ? 6 : -1);
     if (a.W == 4) return sk ? 14 : (a.cin_pad % 16 == 0 ? 7 : -1);

@@ -208,6 +208,18 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     MVLM_CHECK_HIP(ctx, hipMemsetAsync(ctr, 0, ctr_ints * sizeof(int), ctx->stream));
     MVLM_CHECK_HIP(ctx, hipMemsetAsync(keys, 0xFF, key_bytes, ctx->stream));  // RM_KEY_EMPTY everywhere
     const long nv = long(n_views) * V, nt = long(n_views) * T;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->render_profiling) {  // HIP events on the launch stream around the five kernels of this call
+        if (ctx->render_event_cursor + 2 > ctx->render_events.size()) ctx->render_events.resize(ctx->render_event_cursor + 2, nullptr);
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t& e = ctx->render_events[ctx->render_event_cursor + k];
+            if (!e) MVLM_CHECK_HIP(ctx, hipEventCreate(&e));
+        }
+        e0 = ctx->render_events[ctx->render_event_cursor];
+        e1 = ctx->render_events[ctx->render_event_cursor + 1];
+        ctx->render_event_cursor += 2;
+        MVLM_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
     hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, mesh->verts, V,
                        rot, n_views, tv);
     hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris, V,
@@ -218,6 +230,10 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     hipLaunchKernelGGL(tile_kernel, dim3(n_views * TILES), dim3(256), 0, ctx->stream, tv, mesh->tris, mesh->uvs,
                        mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys, ctx->render_shading, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
+    if (e1) {
+        MVLM_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        ctx->render_prof.push_back({n_views, V, T, e0, e1});
+    }
     // the overflow flag travels to pinned host memory without stalling the stream; it is
     // examined by mvlm_render_check (after the caller's own synchronisation point)
     if (!ctx->render_overflow_host)
@@ -233,6 +249,35 @@ extern "C" int mvlm_render_check(mvlm_ctx* ctx) {
     MVLM_REQUIRE(ctx, !ctx->render_overflow_host || *ctx->render_overflow_host == 0,
                  "render: per-view tile lists overflowed (mesh has too many screen-filling triangles)");
     return 0;
+}
+
+extern "C" int mvlm_render_set_profiling(mvlm_ctx* ctx, int enabled) {
+    MVLM_ENTER(ctx);
+    ctx->render_profiling = enabled != 0;
+    ctx->render_prof.clear();
+    ctx->render_event_cursor = 0;
+    return 0;
+}
+
+extern "C" int mvlm_render_get_profile(mvlm_ctx* ctx, int32_t* n_views, int32_t* n_verts, int32_t* n_tris, float* ms,
+                                       int cap) {
+    std::lock_guard<std::mutex> lk(ctx->mu);  // returns a record count, -1 on failure; clears the records
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+    int n = 0;
+    for (const auto& r : ctx->render_prof) {
+        if (n >= cap) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;
+        n_views[n] = r.n_views;
+        n_verts[n] = r.n_verts;
+        n_tris[n] = r.n_tris;
+        ms[n] = t;
+        ++n;
+    }
+    ctx->render_prof.clear();
+    ctx->render_event_cursor = 0;
+    return n;
 }
 
 extern "C" int mvlm_set_render_shading(mvlm_ctx* ctx, int shading) {

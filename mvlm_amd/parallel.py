@@ -35,15 +35,42 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def broadcast_array(arr: np.ndarray | None, src: int = 0) -> np.ndarray:
-    """Broadcast a small host array (pose table, RANSAC draws) from ``src`` to all ranks."""
-    if not is_distributed():
-        return arr
+def _collective_device(device):
+    """Where a tensor collective's payload must live: the rank's own GPU under RCCL ("nccl"), the host under gloo."""
+    import torch
     import torch.distributed as dist
 
-    box = [arr]
-    dist.broadcast_object_list(box, src=src)
-    return box[0]
+    if dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+
+
+def broadcast_array(arr: np.ndarray | None, shape: tuple, device=None, src: int = 0) -> np.ndarray:
+    """Broadcast a small host table of known shape (the pose table) from ``src`` as ONE tensor collective on
+    ``device`` (this rank's GPU under RCCL) - no pickling, no staging on whatever GPU happens to be current.
+    float32 / float64 tables keep their dtype (the 8-view table is float32 in the reference, render3d.py:94-111,
+    and the estimator's rotation arithmetic follows that dtype)."""
+    if not is_distributed():
+        return arr
+    import torch
+    import torch.distributed as dist
+
+    n = int(np.prod(shape))
+    t = torch.zeros(n + 1, dtype=torch.float64, device=_collective_device(device))
+    if dist.get_rank() == src:
+        a = np.asarray(arr)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"broadcast_array: table is {a.shape}, announced {tuple(shape)}")
+        host = np.empty(n + 1, np.float64)
+        host[:n] = a.astype(np.float64).ravel()
+        host[n] = 1.0 if a.dtype == np.float32 else 0.0
+        t.copy_(torch.from_numpy(host))
+    dist.broadcast(t, src=src)
+    host = t.cpu().numpy()
+    out = host[:n].reshape(shape)
+    return out.astype(np.float32) if host[n] == 1.0 else out
 
 
 def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0) -> np.ndarray:
@@ -53,8 +80,7 @@ def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0) 
     import torch
     import torch.distributed as dist
 
-    on_gpu = dist.get_backend() != "gloo"
-    t = torch.zeros(shape, dtype=torch.int32, device=device if on_gpu else "cpu")
+    t = torch.zeros(shape, dtype=torch.int32, device=_collective_device(device))
     if dist.get_rank() == src:
         t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)))
     dist.broadcast(t, src=src)

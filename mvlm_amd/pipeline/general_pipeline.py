@@ -33,31 +33,47 @@ def _drop(box: list) -> None:
     box.clear()
 
 
-class TimeMixin:
-    def __init__(self):
-        self.start_time = time.time()
-        self.end_time = None
+class StageTimer:
+    """Wall-clock seconds per stage of the last call, under the reference's stage names
+    (the reference prints them through tic/toc, general_pipeline.py:84-111; here they are kept
+    as a dict so callers and bench.py can read them, and printed in the same wording when verbose)."""
 
-    def tic(self):
-        self.start_time = time.time()
+    LABELS = {"render": "Render [Total]: ", "prediction": "Prediction [Total]: ",
+              "lines": "Landmarks [0] - From Heatmaps: ", "consensus": "Landmarks [1] - From View Lines: ",
+              "project": "Landmarks [2] - Project to Surface: ", "total": "Landmarks 3D Total: "}
 
-    def toc(self):
-        self.end_time = time.time()
-        return self.end_time - self.start_time
+    def __init__(self, sink: dict, say):
+        self.sink, self.say = sink, say
 
-    def toc_p(self):
-        return self.p_time(self.toc())
+    @staticmethod
+    def fmt(seconds: float) -> str:
+        return f"{seconds:08.6f} s"
 
-    def p_time(self, t):
-        return f"{t:08.6f} s"
+    def stage(self, name: str):
+        return _Stage(self, name)
 
 
-class Pipeline(abc.ABC, TimeMixin):
+class _Stage:
+    def __init__(self, timer: StageTimer, name: str):
+        self.timer, self.name = timer, name
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        dt = time.perf_counter() - self.t0
+        self.timer.sink[self.name] = dt
+        if exc[0] is None:
+            self.timer.say(StageTimer.LABELS.get(self.name, self.name + ": "), StageTimer.fmt(dt))
+        return False
+
+
+class Pipeline(abc.ABC):
     def __init__(self, render_image_stack: bool = False, offscreen: bool = True, n_views: int = 8,
                  render_image_folder: Path | None = None, visualize_rays: bool = False,
                  screenshot_folder: Path | None = None, device: int = 0, shard_views: bool = False,
                  verbose: bool = True):
-        TimeMixin.__init__(self)
         self.render_image_stack = render_image_stack
         self.render_image_folder = render_image_folder
         self.n_views = n_views
@@ -67,12 +83,19 @@ class Pipeline(abc.ABC, TimeMixin):
         self.shard_views = shard_views
         self.verbose = verbose
         self.timings: dict[str, float] = {}
+        self._timer = StageTimer(self.timings, self._say)
         self.last_error: float | None = None
         self._rays = None  # (mesh, starts, ends) of the current call when visualize_rays is set
         # optional "pre-align" block of a Deep-MVLM config (mvlm_amd/utils/prealign.py); the
         # reference's live pipeline has none (it renders the mesh as-is)
         self.pre_align: dict | None = None
 
+        if shard_views:
+            # one process per GPU: collectives (RCCL) and the allocator must use THIS rank's device, not cuda:0
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device)
         self.renderer_3d = HipRenderer3D(image_size=(256, 256), offscreen=offscreen, n_views=n_views, device=device,
                                          verbose=verbose)
         self.estimator_3d = HipEstimator3D(device=device, verbose=verbose)
@@ -88,31 +111,39 @@ class Pipeline(abc.ABC, TimeMixin):
             print(*a)
 
     def _fusable(self) -> bool:
+        # any predictor that can hand over device-resident maxima for every view (HipPaulsenModel; a
+        # PrecomputedPredictor built with ``device_fn``) keeps the whole call in HBM
+        p2 = self.predictor_2d
+        device_predictor = isinstance(p2, HipPaulsenModel) or callable(getattr(p2, "predict_device", None))
         return (isinstance(self.renderer_3d, HipRenderer3D) and isinstance(self.estimator_3d, HipEstimator3D)
-                and isinstance(self.predictor_2d, HipPaulsenModel))
+                and device_predictor)
 
     def predict_one_file(self, file_name: Path, landmark_indices: list[int] | None = None,
                          view_indices: list[int] | None = None, clip_rays_to_mesh: bool = True):
         if self.predictor_2d is None:
             raise ValueError("Predictor2D is not initialized.")
         file_name = Path(file_name)
-        full_s = time.time()
         if not file_name.exists():
             print(f"File {file_name} does not exist")
             return None
         self._rays = None
-        if self._fusable():
-            landmarks = self._predict_fused(file_name)
-        else:
-            landmarks = self._predict_slots(file_name)
-        self._say("Landmarks 3D Total: ", self.p_time(time.time() - full_s))
+        with self._timer.stage("total"):
+            if self._fusable():
+                landmarks = self._predict_fused(file_name)
+            else:
+                landmarks = self._predict_slots(file_name)
+        self._after_prediction(file_name, landmarks, landmark_indices, view_indices, clip_rays_to_mesh)
+        return landmarks
+
+    def _after_prediction(self, file_name, landmarks, landmark_indices=None, view_indices=None, clip_rays_to_mesh=True):
+        """What follows every prediction, whichever entry point made it (predict_one_file, predict_files):
+        the optional ray dump (general_pipeline.py:111-130) and the reset of the per-call ray state."""
         if self.visualize_rays and self._rays is not None:
             try:
                 self.dump_rays(file_name, landmarks, landmark_indices, view_indices, clip_rays_to_mesh)
             except Exception as e:  # noqa: BLE001 - general_pipeline.py:129-130: a failed visualisation never fails the call
                 print(f"[Pipeline] Ray visualization failed: {e}")
         self._rays = None
-        return landmarks
 
     def dump_rays(self, file_name: Path, landmarks, landmark_indices=None, view_indices=None, clip_to_mesh: bool = True):
         """What the reference hands to its VTK ``RayVisualizer`` (general_pipeline.py:111-128), written
@@ -139,7 +170,9 @@ class Pipeline(abc.ABC, TimeMixin):
     def predict_mesh_device(self, mesh, transform_stack):
         """Render + network + fusion + snap for an already loaded mesh and pose table.
         Returns (landmarks [NL,3] float64 numpy, mean RANSAC error).  With
-        ``shard_views`` under torch.distributed each rank handles a slice of the views."""
+        ``shard_views`` under torch.distributed each rank handles a slice of the views
+        (a rank whose slice is empty - more ranks than views - skips render and network
+        but still joins the collectives)."""
         import torch
 
         r3, p2, e3 = self.renderer_3d, self.predictor_2d, self.estimator_3d
@@ -151,51 +184,46 @@ class Pipeline(abc.ABC, TimeMixin):
         from ..utils.render3d import view_rotations
 
         rot = view_rotations(transform_stack)  # once per call: renderer and estimator share it
-        t0 = time.time()
-        images = r3.render_device(mesh, transform_stack[lo:hi], rot=rot[lo:hi])
-        if self.verbose:
-            torch.cuda.synchronize()
-        self.timings["render"] = time.time() - t0
-        self._say("Render [Total]: ", self.p_time(self.timings["render"]))
-        if self.render_image_stack:
+        tm = self._timer
+        with tm.stage("render"):
+            images = r3.render_device(mesh, transform_stack[lo:hi], rot=rot[lo:hi]) if hi > lo else None
+            if self.verbose:
+                torch.cuda.synchronize()
+        if self.render_image_stack and images is not None:
             self.visualize_image_stack(images.cpu().numpy(), mesh.path or Path("mesh.obj"), first_index=lo)
 
-        t0 = time.time()
-        maxima = p2.predict_device(images)
-        del images
-        if sharded:
-            maxima = parallel.all_gather_views(maxima, n_total)
-        if self.verbose:
-            torch.cuda.synchronize()
-        self.timings["prediction"] = time.time() - t0
-        self._say("Prediction [Total]: ", self.p_time(self.timings["prediction"]))
+        with tm.stage("prediction"):
+            if images is not None:
+                maxima = p2.predict_device(images)
+            else:
+                maxima = torch.empty((p2.get_lm_count(), 0, 3), dtype=torch.float32,
+                                     device=torch.device("cuda", self.device))
+            del images
+            if sharded:
+                maxima = parallel.all_gather_views(maxima, n_total)
+            if self.verbose:
+                torch.cuda.synchronize()
 
-        t0 = time.time()
-        starts, ends = e3.lines_device(maxima, transform_stack, 256, rot=rot)
-        self.timings["lines"] = time.time() - t0
-        self._say("Landmarks [0] - From Heatmaps: ", self.p_time(self.timings["lines"]))
+        with tm.stage("lines"):
+            starts, ends = e3.lines_device(maxima, transform_stack, 256, rot=rot)
 
-        t0 = time.time()
-        draws_fn = None
-        if sharded:
-            # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) from the survivor
-            # counts every rank computed, and broadcasts the [NL, 8] index table
-            def draws_fn(counts):
-                draws = e3.draw_ransac_indices(counts) if rank == 0 else None
-                return parallel.broadcast_int32(draws, (len(counts), 8), maxima.device)
+        with tm.stage("consensus"):
+            draws_fn = None
+            if sharded:
+                # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) from the survivor
+                # counts every rank computed, and broadcasts the [NL, 8] index table
+                def draws_fn(counts):
+                    draws = e3.draw_ransac_indices(counts) if rank == 0 else None
+                    return parallel.broadcast_int32(draws, (len(counts), 8), maxima.device)
 
-        if self.visualize_rays:
-            self._rays = (mesh, starts.cpu().numpy(), ends.cpu().numpy())
-        out, err, _ = e3.consensus_device(maxima, starts, ends, draws_fn=draws_fn)
-        error = e3.mean_error(err.cpu().numpy())
-        self.timings["consensus"] = time.time() - t0
-        self._say("Landmarks [1] - From View Lines: ", self.p_time(self.timings["consensus"]))
+            if self.visualize_rays:
+                self._rays = (mesh, starts.cpu().numpy(), ends.cpu().numpy())
+            out, err, _ = e3.consensus_device(maxima, starts, ends, draws_fn=draws_fn)
+            error = e3.mean_error(err.cpu().numpy())
 
-        t0 = time.time()
-        landmarks = e3.project_device(mesh, out).cpu().numpy()
-        r3.check()  # deferred renderer status (the .cpu() above already synchronised)
-        self.timings["project"] = time.time() - t0
-        self._say("Landmarks [2] - Project to Surface: ", self.p_time(self.timings["project"]))
+        with tm.stage("project"):
+            landmarks = e3.project_device(mesh, out).cpu().numpy()
+            r3.check()  # deferred renderer status (the .cpu() above already synchronised)
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error
         return landmarks, error
@@ -207,7 +235,8 @@ class Pipeline(abc.ABC, TimeMixin):
         work back to back.  Here a reader thread parses the next ``prefetch`` OBJ/JPEG pairs
         (native reader + libjpeg, both outside the GIL) while the GPU works on the current scan,
         so a folder runs at the GPU rate.  Results equal the sequential loop's: poses and RANSAC
-        draws are taken on the calling thread in file order."""
+        draws are taken on the calling thread in file order, and every scan gets the same
+        post-step (ray dump) as ``predict_one_file``."""
         from concurrent.futures import ThreadPoolExecutor
 
         from ..utils.mesh_io import load_obj
@@ -230,25 +259,26 @@ class Pipeline(abc.ABC, TimeMixin):
             for i, f in enumerate(files):
                 if i + prefetch < len(files):
                     pending.append(pool.submit(ingest, files[i + prefetch]))
-                full_s = time.time()
                 mesh = pending.pop(0).result()  # re-raises the reader's ValueError / FileNotFoundError
                 if mesh is None:
                     print(f"File {f} does not exist")
                     yield f, None
                     continue
-                landmarks = self._predict_fused(f, mesh=mesh)
+                self._rays = None
+                with self._timer.stage("total"):
+                    landmarks = self._predict_fused(f, mesh=mesh)
+                self._after_prediction(f, landmarks)
                 # returning a scan's 10-25 MB of host arrays to the OS costs milliseconds (page
                 # unmapping under the GPU driver's MMU notifier): let the reader thread drop them
                 # while this thread goes on to the next scan
                 pool.submit(_drop, [mesh])
                 del mesh
-                self._say("Landmarks 3D Total: ", self.p_time(time.time() - full_s))
                 yield f, landmarks
 
     def _predict_fused(self, file_name: Path, mesh=None):
         from ..utils.mesh_io import load_obj
 
-        self.tic()
+        t0 = time.perf_counter()
         if mesh is None:
             file_name = self.renderer_3d._check_file(file_name)
             mesh = load_obj(file_name)
@@ -256,10 +286,10 @@ class Pipeline(abc.ABC, TimeMixin):
         if sharded:
             rank, _ = parallel.rank_world()
             poses = self.renderer_3d.generate_3d_transformations() if rank == 0 else None
-            poses = parallel.broadcast_array(poses)
+            poses = parallel.broadcast_array(poses, (int(self.renderer_3d.n_views), 6), device=self.device)
         else:
             poses = self.renderer_3d.generate_3d_transformations()
-        self.timings["load"] = self.toc()
+        self.timings["load"] = time.perf_counter() - t0
         matrix = None
         if self.pre_align and any(self.pre_align.get(k) for k in ("align_center_of_mass", "rot_x", "rot_y", "rot_z")) \
                 or (self.pre_align and float(self.pre_align.get("scale", 1)) != 1.0):
@@ -275,28 +305,24 @@ class Pipeline(abc.ABC, TimeMixin):
 
     # ---- the reference's numpy slot protocol (general_pipeline.py:83-108) ----------------
     def _predict_slots(self, file_name: Path):
-        self.tic()
-        image_stack, transform_stack, pd = self.renderer_3d.multiview_render(file_name)
-        self._say("Render [Total]: ", self.toc_p())
+        tm = self._timer
+        with tm.stage("render"):
+            image_stack, transform_stack, pd = self.renderer_3d.multiview_render(file_name)
         if self.render_image_stack:
             self.visualize_image_stack(image_stack, file_name)
-        self.tic()
-        landmark_stack, valid = self.predictor_2d.predict_landmarks_from_images(image_stack)
-        self._say("Prediction [Total]: ", self.toc_p())
+        with tm.stage("prediction"):
+            landmark_stack, valid = self.predictor_2d.predict_landmarks_from_images(image_stack)
         landmark_stack = landmark_stack[:, valid, :]
         transform_stack = transform_stack[valid]
         image_stack = image_stack[valid]
-        self.tic()
-        lines_s, lines_e = self.estimator_3d.estimate_landmark_lines(image_stack, landmark_stack, transform_stack)
-        self._say("Landmarks [0] - From Heatmaps: ", self.toc_p())
+        with tm.stage("lines"):
+            lines_s, lines_e = self.estimator_3d.estimate_landmark_lines(image_stack, landmark_stack, transform_stack)
         if self.visualize_rays:
             self._rays = (pd, np.asarray(lines_s), np.asarray(lines_e))
-        self.tic()
-        landmarks, error = self.estimator_3d.estimate_landmarks_from_lines(landmark_stack, lines_s, lines_e)
-        self._say("Landmarks [1] - From View Lines: ", self.toc_p())
-        self.tic()
-        landmarks = self.estimator_3d.project_landmarks_to_surface(pd, landmarks)
-        self._say("Landmarks [2] - Project to Surface: ", self.toc_p())
+        with tm.stage("consensus"):
+            landmarks, error = self.estimator_3d.estimate_landmarks_from_lines(landmark_stack, lines_s, lines_e)
+        with tm.stage("project"):
+            landmarks = self.estimator_3d.project_landmarks_to_surface(pd, landmarks)
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error
         return landmarks

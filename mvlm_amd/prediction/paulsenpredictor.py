@@ -97,15 +97,18 @@ class HipPaulsenModel(Predictor2D):
         for p in candidates:
             if p.is_file():
                 return W.load_state_dict_file(p)
-        # same fallback as the reference (:94-101): fetch into the package's models folder
-        from torch.hub import load_state_dict_from_url
+        # same fallback as the reference (:94-101): fetch into the package's models folder.  The file
+        # names carry the sha256 prefix torch.hub verifies (check_hash); the downloaded file then goes
+        # through the same safe loader (weights_only, "module." prefix handling) as a local checkpoint
+        from torch.hub import download_url_to_file
 
         if self.verbose:
             print("Loading checkpoint")
-        ckpt = load_state_dict_from_url(_URL_ROOT + name, model_dir=str(Path(__file__).parent / "models"),
-                                        map_location="cpu")
-        sd = ckpt["state_dict"] if name.find("only_state_dict") == -1 else ckpt
-        return {k: v.numpy() for k, v in sd.items()}
+        target = Path(__file__).parent / "models" / name
+        target.parent.mkdir(parents=True, exist_ok=True)
+        hash_prefix = name.rsplit("-", 1)[1].split(".")[0]
+        download_url_to_file(_URL_ROOT + name, str(target), hash_prefix=hash_prefix, progress=self.verbose)
+        return W.load_state_dict_file(target)
 
     # ---- inference --------------------------------------------------------------------
     def _batch_for(self, n_views: int) -> int:

@@ -15,12 +15,12 @@ from . import cnn, estimator, raster, surface
 
 
 def predict_mesh(mesh_verts, mesh_tris, mesh_uvs, mesh_tex, transform_stack, state_dict, chan_sel,
-                 mode="quantile", q=0.5, thr=0.5, batch_size=2, timings: dict | None = None):
+                 mode="quantile", q=0.5, thr=0.5, batch_size=2, timings: dict | None = None, shading: str = "texture"):
     """-> (landmarks [NL,3] f64, mean error, intermediates dict).  Uses the global numpy RNG
     for the RANSAC draw like the reference (seed it for reproducibility)."""
     t = timings if timings is not None else {}
     t0 = time.time()
-    images = raster.multiview_render(mesh_verts, mesh_tris, mesh_uvs, mesh_tex, transform_stack)
+    images = raster.multiview_render(mesh_verts, mesh_tris, mesh_uvs, mesh_tex, transform_stack, shading=shading)
     t["render"] = time.time() - t0
     t0 = time.time()
     lms, valid = cnn.predict_landmarks_from_images(state_dict, images, chan_sel, batch_size=batch_size)

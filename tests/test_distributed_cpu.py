@@ -26,7 +26,10 @@ def _worker(rank, world, port, n_total, nl, q):
     lo, hi = parallel.shard_range(n_total, rank, world)
     got = parallel.all_gather_views(full[:, lo:hi].contiguous(), n_total)
     poses = np.arange(12.0).reshape(4, 3) if rank == 0 else None
-    poses = parallel.broadcast_array(poses)
+    poses = parallel.broadcast_array(poses, (4, 3))
+    p32 = parallel.broadcast_array(np.arange(48, dtype=np.float32).reshape(8, 6) if rank == 0 else None, (8, 6))
+    assert p32.dtype == np.float32 and poses.dtype == np.float64  # the 8-view table stays float32 (render3d.py:94-111)
+    assert np.array_equal(p32, np.arange(48, dtype=np.float32).reshape(8, 6))
     draws = np.arange(nl * 8, dtype=np.int32).reshape(nl, 8) * 3 if rank == 0 else None
     draws = parallel.broadcast_int32(draws, (nl, 8), torch.device("cpu"))  # the RANSAC index table of rank 0
     ok_draws = draws.dtype == np.int32 and np.array_equal(draws, np.arange(nl * 8).reshape(nl, 8) * 3)

@@ -1,0 +1,261 @@
+"""Round-2 GPU parity additions: the renderer against the reference estimator's rays and the analytic
+scenes, the end-to-end matrix over the BASELINE configurations' networks (C = 1, 2, 3, 4 through
+``pipeline_from_config``), the planted-peak case through all convolutions, rank-deficient LSQ goldens on
+the GPU solver, NaN landmarks in the snap, and the conv tiles only big device batches reach.
+Everything calls through the C ABI (libmvlm_hip.so).  Run with -m gpu."""
+import contextlib
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import planted
+import test_oracle_pinning as pin
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def hip_render(verts, tris, uvs, tex, poses, shading="texture"):
+    from mvlm_amd.utils import HipRenderer3D, Mesh
+
+    r = HipRenderer3D(n_views=int(poses.shape[0]), verbose=False, shading=shading)
+    m = Mesh(np.asarray(verts, np.float32), np.asarray(tris, np.int32), uvs, tex)
+    out = r.render_device(m, np.asarray(poses)).cpu().numpy()
+    r.check()
+    return out
+
+
+# ---- renderer: pinned scenes ---------------------------------------------------------------------
+def test_hip_renderer_on_reference_estimator_rays(golden):
+    """Markers spanned by the REFERENCE estimator's rays (tests/golden/marker_rays.npz) are drawn by the HIP
+    rasteriser at exactly their pixels, for 12 random rotations and the fixed 8-view table: rotation order,
+    vertical flip and pixel centres of the product renderer are pinned to reference code."""
+    from oracle import raster
+
+    g = golden("marker_rays.npz")
+    poses = g["poses"]
+    for view in range(poses.shape[0]):
+        verts, tris = pin.marker_scene(g, view)
+        img = hip_render(verts, tris, None, None, poses[view:view + 1])[0]
+        pin.check_marker_view(img, g, view)
+        np.testing.assert_array_equal(img, raster.multiview_render(verts, tris, None, None, poses[view:view + 1])[0])
+
+
+def test_hip_renderer_analytic_scenes():
+    """The hand-computed scenes of tests/test_oracle_pinning.py through the HIP rasteriser."""
+    for z0 in (-103.0, 10.0, 143.0):
+        x0, x1, y0, y1 = -50.0, 61.0, -20.0, 33.0
+        verts, tris, _ = pin.quad(x0, x1, y0, y1, z0)
+        img = hip_render(verts, tris, None, None, pin.IDENTITY)[0]
+        want = np.tile(pin.BG, (256, 256, 1))
+        rows = [255 - j for j in pin.covered(*pin.window([y0, y1]))]
+        want[np.ix_(rows, pin.covered(*pin.window([x0, x1])))] = [1.0, 1.0, 1.0, pin.depth_byte(z0) / 255.0]
+        np.testing.assert_array_equal(img, want.astype(np.float32))
+    tex = np.array([[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [255, 255, 0]]], np.uint8)
+    verts, tris, uvs = pin.quad(-60, 60, -60, 60, 0.0, [[0, 0], [2, 0], [2, 2], [0, 2]])
+    rgb = np.rint(hip_render(verts, tris, uvs, tex, pin.IDENTITY)[0][..., :3] * 255).astype(int)
+    assert rgb[170, 85].tolist() == [0, 0, 255] and rgb[170, 110].tolist() == [255, 255, 0]
+    assert rgb[170, 135].tolist() == [0, 0, 255] and rgb[145, 85].tolist() == [255, 0, 0]
+
+
+def test_depth_plane_is_the_first_ray_hit_for_rotated_poses():
+    """mvlm_clip_rays_to_mesh along the rays of ROTATED views ends where each view's depth plane says the surface
+    is: ties renderer (pose, flip, depth quantisation) and estimator rays together away from the identity pose."""
+    from mvlm_amd.utils import HipEstimator3D, HipRenderer3D, view_rotations
+    from mvlm_amd.utils.synthetic import face_like_mesh
+
+    m = face_like_mesh(70, 32, 8)
+    poses = np.array([[25.0, -40.0, 15.0, 0, 0, 0], [-35.0, 62.0, -18.0, 0, 0, 0], [30.0, 15.0, 0.0, 0, 0, 0]])
+    r = HipRenderer3D(n_views=3, verbose=False)
+    e3 = HipEstimator3D(verbose=False)
+    imgs = r.render_device(m, poses).cpu().numpy()
+    rot = view_rotations(poses).reshape(-1, 3, 3)
+    rows, cols = np.meshgrid(np.arange(20, 236, 7), np.arange(20, 236, 7), indexing="ij")
+    # centre of pixel (row, col) in the maxima convention (row - 1, col - 0.5): (row - 0.5, col)
+    px = np.stack([rows.ravel() - 0.5, cols.ravel() + 0.0, np.ones(rows.size)], axis=1).astype(np.float32)
+    lms = np.repeat(px[:, None, :], 3, axis=1)
+    s, e = e3.estimate_landmark_lines(np.zeros((3, 256, 256, 4), np.float32), lms, poses)
+    ends, hit = e3.clip_rays_to_mesh(m, s, e)
+    for v in range(3):
+        depth = np.rint(imgs[v, rows.ravel(), cols.ravel(), 3] * 255).astype(int)
+        z_view = ends[:, v] @ rot[v].T[:, 2]                                  # (M p).z
+        expect = np.array([pin.depth_byte(z) for z in z_view])
+        inside = hit[:, v]
+        assert inside.mean() > 0.25
+        assert (np.abs(depth[inside] - expect[inside]) <= 1).mean() > 0.95     # silhouette pixels: centre vs. sub-pixel ray
+        assert (depth[~inside] == 1).mean() > 0.95
+
+
+# ---- end-to-end matrix ---------------------------------------------------------------------------
+def _e2e_config(dataset, mode, n_views, grid, seed):
+    from mvlm_amd import arch, config, weights
+    from mvlm_amd.pipeline import pipeline_from_config
+    from mvlm_amd.utils.synthetic import face_like_mesh
+    from oracle import pipeline as opipe
+
+    cfg = config.default_config(dataset, mode, n_views=n_views)
+    pipe = pipeline_from_config(cfg, weights=f"synthetic:{seed}", verbose=False)
+    nl, c = pipe.get_lm_count(), arch.IMAGE_CHANNELS[mode]
+    mesh = face_like_mesh(grid, 128, seed)
+    np.random.seed(0)
+    poses = pipe.renderer_3d.generate_3d_transformations()
+    np.random.seed(1)
+    got, gerr = pipe.predict_mesh_device(mesh, poses)
+    sd = weights.synthetic_state_dict(nl, c, seed=seed)
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        want, werr, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses, sd,
+                                               arch.CHANNEL_SELECT[mode],
+                                               shading="geometry" if "geometry" in mode else "texture")
+    images = pipe.renderer_3d.render_device(mesh, poses)
+    np.testing.assert_array_equal(images.cpu().numpy(), inter["images"])
+    gmax = pipe.predictor_2d.predict_device(images).cpu().numpy()
+    return got, gerr, want, werr, inter, gmax
+
+
+@pytest.mark.parametrize("dataset,mode,n_views,grid", [
+    ("BU_3DFE", "depth", 8, 51),              # BASELINE configs[0]: C = 1, the fixed 8-view table
+    ("DTU3D", "RGB", 64, 224),                # configs[1]: C = 3, 64 views, ~100k triangles
+    ("DTU3D", "geometry+depth", 12, 60),      # configs[3]'s per-GPU shard: C = 2, 12 views, geometry shading
+    ("BU_3DFE", "RGB+depth", 16, 60),         # configs[2]'s network (C = 4, 84 landmarks)
+])
+def test_end_to_end_config_matrix_against_oracle(dataset, mode, n_views, grid):
+    got, gerr, want, werr, inter, gmax = _e2e_config(dataset, mode, n_views, grid, 13)
+    diff_views = ~np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)      # [NL, N]
+    assert diff_views.mean() < 0.02                  # argmax near-ties only (summation order differs from oneDNN)
+    same = ~diff_views.any(axis=1)
+    assert same.mean() > 0.5
+    assert np.abs(got[same] - want[same]).max() < 1e-3   # BASELINE north_star: 1e-3 model units
+    assert np.abs(got - want).max() < 2.5
+
+
+def test_planted_peaks_through_the_network():
+    """SURVEY.md 8(d) planted peak THROUGH conv11: the hand-made detector (tests/planted.py) makes every landmark
+    channel peak at a known surface point, so render -> 138 convs -> fused argmax -> rays -> quantile filter ->
+    RANSAC *inlier* refit -> snap runs end to end on the GPU and is compared with the oracle and the truth."""
+    from mvlm_amd import arch, config
+    from mvlm_amd.pipeline import pipeline_from_config
+    from oracle import pipeline as opipe
+    from test_planted_cpu import planted_scene
+
+    mesh, pts, sd, poses = planted_scene(n_views=16)
+    pipe = pipeline_from_config(config.default_config("DTU3D", "RGB", n_views=16), weights=sd, verbose=False)
+    np.random.seed(1)
+    got, gerr = pipe.predict_mesh_device(mesh, poses)
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        want, werr, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses, sd,
+                                               arch.CHANNEL_SELECT["RGB"])
+    assert werr < 10.0 and gerr < 10.0               # inlier branch for every landmark (a fallback adds 1e8 / NL)
+    gmax = pipe.predictor_2d.predict_device(pipe.renderer_3d.render_device(mesh, poses)).cpu().numpy()
+    same_px = np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)
+    assert same_px.mean() > 0.99
+    same = same_px.all(axis=1)
+    assert same.mean() > 0.8
+    assert np.abs(got[same] - want[same]).max() < 1e-3
+    assert abs(gerr - werr) < 1e-6 * max(1.0, werr) or not same.all()
+    d = np.linalg.norm(got - pts, axis=1)
+    assert d.max() < 6.0 and np.median(d) < 4.0      # the planted points are found (offset: see test_planted_cpu)
+
+
+# ---- consensus: the LSQ goldens (rank-deficient systems) on the GPU solver --------------------------
+@pytest.mark.parametrize("tag", ["k0", "k1", "k2", "parallel", "k6"])
+def test_lsq_goldens_on_the_gpu_solver(golden, tag):
+    """compute_intersection_between_lines (utils3d.py:99-124, pinv with numpy's cutoff) as reproduced by the
+    GPU's Jacobi pseudo-inverse: 0 / 1 / 2 lines (k < 3: plain LSQ, estimator3d.py:174-176), three PARALLEL
+    lines (rank 2) and a generic bundle (both through the one-shot RANSAC, all lines inliers -> refit on all)."""
+    from mvlm_amd.utils import HipEstimator3D
+
+    g = golden("estimator.npz")
+    pa, pb, want = g[f"lsq_{tag}_pa"], g[f"lsq_{tag}_pb"], g[f"lsq_{tag}_p"]
+    if tag == "parallel":
+        # the golden lines are 10 and 7 units apart: with the inlier rule dist^2 < 100 (estimator3d.py:97) the
+        # one-shot draw would decide which of them are refitted.  The LSQ point is equivariant under uniform
+        # scaling, so the same rank-2 system at half size (5 and 3.5 apart: every line an inlier for any draw)
+        # must give half the reference's point.
+        pa, pb, want = 0.5 * pa, 0.5 * pb, 0.5 * want
+    k = pa.shape[0]
+    n = k + 2                                        # two extra views whose score fails the absolute threshold
+    s = np.zeros((1, n, 3))
+    e = np.ones((1, n, 3))
+    s[0, 1:1 + k], e[0, 1:1 + k] = pa, pb
+    lms = np.zeros((1, n, 3), np.float32)
+    lms[0, 1:1 + k, 2] = 0.9
+    lms[0, [0, n - 1], 2] = 0.1
+    e3 = HipEstimator3D(mode="absolute", threshold_absolute=0.5, verbose=False)
+    np.random.seed(0)
+    out, err = e3.estimate_landmarks_from_lines(lms, s, e)
+    np.testing.assert_allclose(out[0], want, rtol=0, atol=1e-8)
+    if k >= 3:
+        assert err < 1e8                             # inlier branch
+
+
+def test_snap_passes_non_finite_landmarks_through():
+    """A NaN landmark (non-finite heatmaps / weights upstream) has no nearest triangle: it is returned as it
+    came (the CPU oracle's arithmetic gives NaN as well), never uninitialised memory; its neighbours are unaffected."""
+    from mvlm_amd.utils import HipEstimator3D
+    from mvlm_amd.utils.synthetic import face_like_mesh
+    from oracle import surface
+
+    m = face_like_mesh(40, 16, 2)
+    pts = np.array([[0.0, 0.0, 80.0], [np.nan, 1.0, 2.0], [10.0, -20.0, 5.0], [np.inf, 0.0, 0.0]])
+    e3 = HipEstimator3D(verbose=False)
+    for _ in range(2):                               # twice: a stale value from the first call must not show up
+        got = e3.project_landmarks_to_surface(m, pts)
+    want = surface.project_landmarks_to_surface(m.verts, m.tris, pts[[0, 2]])
+    np.testing.assert_allclose(got[[0, 2]], want, rtol=0, atol=1e-9)
+    assert np.isnan(got[1]).any() and not np.isfinite(got[3]).all()
+
+
+# ---- conv tiles that only device batches > 128 views reach -------------------------------------------
+@pytest.mark.parametrize("cin,cout,size,batch", [(256, 128, 8, 129), (64, 64, 8, 130), (256, 128, 4, 513), (128, 64, 16, 33)])
+def test_conv_tiles_of_large_device_batches(cin, cout, size, batch):
+    """8x8 / 4x4 hourglass levels leave the split-K tiles above 8192 pixels per level (device_batch > 128):
+    the image-folding tiles conv3x3_c32_t8x8x2 / t4x4x8 (and t8x16 at 16x16) against torch float64."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    rs = np.random.RandomState(cin + size + batch)
+    x = rs.standard_normal((batch, cin, size, size)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32))
+    res = rs.standard_normal((batch, cout, size, size)).astype(np.float32)
+    xd, rd = dev(x), dev(res)
+    yd = torch.empty((batch, cout, size, size), dtype=torch.float32, device="cuda")
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
+                                  p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())))
+    t = torch.relu(torch.from_numpy(x).double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
+                   + torch.from_numpy(pre[1]).double()[None, :, None, None])
+    want = (torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None, 1, 1) + torch.from_numpy(res).double()).numpy()
+    assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+
+
+def test_visualize_image_stack_writes_the_views(tmp_path):
+    """--visualize-method (general_pipeline.py:133-146): one PNG per view, RGB planes * 255 as uint8."""
+    from PIL import Image
+
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    obj = write_face_like_obj(tmp_path / "face.obj", grid=30, tex_size=32, seed=1)
+    out = tmp_path / "png"
+    out.mkdir()
+    pipe = pipeline.create_pipeline("dtu3d", n_views=8, weights="synthetic:1", verbose=False, render_image_stack=True,
+                                    render_image_folder=out)
+    np.random.seed(1)
+    assert pipe.predict_one_file(obj) is not None
+    stack, _, _ = pipe.renderer_3d.multiview_render(obj)
+    files = sorted(out.glob("face_*.png"))
+    assert [f.name for f in files] == [f"face_{i:02d}.png" for i in range(8)]
+    for i, f in enumerate(files):
+        np.testing.assert_array_equal(np.asarray(Image.open(f)), np.uint8(stack[i, :, :, 0:3] * 255))
+    pipe.render_image_folder = tmp_path / "does_not_exist"
+    with pytest.raises(ValueError, match="does not exist"):
+        pipe.predict_one_file(obj)

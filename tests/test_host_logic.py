@@ -304,3 +304,23 @@ def test_cli_shards_scans_across_ranks():
     parts = [shard_files(files, r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == sorted(files) and parts[0] == ["s0.obj", "s4.obj", "s8.obj"]
     assert shard_files(files, 0, 1) == files
+
+
+def test_visualize_image_stack_png_dump(tmp_path):
+    """general_pipeline.py:133-146: `<stem>_<ii>.png` per view from the RGB planes, ValueError for a missing folder."""
+    import types
+
+    from PIL import Image
+
+    from mvlm_amd.pipeline.general_pipeline import Pipeline
+
+    rs = np.random.RandomState(0)
+    stack = (rs.randint(0, 256, (3, 256, 256, 4)) / 255).astype(np.float32)
+    me = types.SimpleNamespace(render_image_folder=tmp_path)
+    Pipeline.visualize_image_stack(me, stack, tmp_path / "scan.obj", first_index=4)
+    for i in range(3):
+        png = np.asarray(Image.open(tmp_path / f"scan_{4 + i:02d}.png"))
+        np.testing.assert_array_equal(png, np.uint8(stack[i, :, :, 0:3] * 255))
+    me.render_image_folder = tmp_path / "missing"
+    with pytest.raises(ValueError, match="does not exist"):
+        Pipeline.visualize_image_stack(me, stack, tmp_path / "scan.obj")

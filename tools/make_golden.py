@@ -288,6 +288,42 @@ def gen_estimator(u3, e3, r3, out: Path):
     np.savez_compressed(out / "estimator.npz", **res)
 
 
+def gen_marker_rays(e3, r3, out: Path):
+    """Ties the RENDERER's pose / pixel convention to the reference ESTIMATOR (estimator3d.py:31-90):
+    for seeded rotated poses and argmax pixels (row R, col C) the reference's rays through the four
+    sub-pixel corners (R-1 +- 0.75, C-0.5 +- 0.75) of a 1.5-pixel square around the maximum's ray.
+    A quad spanned by points on those four rays must be rasterised at exactly the pixels the square
+    covers (tests/test_oracle_pinning.py): rotation order, y flip and pixel centres are then pinned
+    to reference code, not to this repo's own restatement."""
+    res = {}
+    rs = np.random.RandomState(77)
+    r = r3.ObjVTKRenderer3D.__new__(r3.ObjVTKRenderer3D)
+    r.__dict__.update(dict(n_views=12, min_x_angle=-40, max_x_angle=40, min_y_angle=-80, max_y_angle=80,
+                           min_z_angle=-20, max_z_angle=20, min_scale=1.4, max_scale=1.9,
+                           min_tx=-20, max_tx=20, min_ty=-20, max_ty=20))
+    np.random.seed(5)
+    poses = r.generate_3d_transformations()          # seeded random rotations about all three axes
+    poses8 = r3.ObjVTKRenderer3D.__new__(r3.ObjVTKRenderer3D)
+    poses8.__dict__.update(dict(n_views=8))
+    poses = np.concatenate([poses, poses8.generate_3d_transformations().astype(np.float64)])  # + the fixed 8-view table
+    n = poses.shape[0]
+    k = 6                                             # markers per view
+    rows = rs.randint(40, 216, (k, n))
+    cols = rs.randint(40, 216, (k, n))
+    corners = np.array([[-0.75, -0.75], [-0.75, 0.75], [0.75, 0.75], [0.75, -0.75]])
+    lms = np.empty((k * 4, n, 3), np.float32)
+    for c in range(4):
+        lms[c::4, :, 0] = rows - 1 + corners[c, 0]    # the maxima convention (row - 1, col - 0.5), paulsenpredictor.py:127
+        lms[c::4, :, 1] = cols - 0.5 + corners[c, 1]
+    lms[:, :, 2] = 1.0
+    est = e3.Estimator3D()
+    s, e = est.estimate_landmark_lines(np.zeros((n, 256, 256, 4), np.float32), lms, poses)
+    res["poses"], res["rows"], res["cols"] = poses, rows, cols
+    res["corner_lms"], res["corner_s"], res["corner_e"] = lms, s, e
+    np.savez_compressed(out / "marker_rays.npz", **res)
+    print("marker rays", s.shape)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(REPO / "tests/golden"))
@@ -309,6 +345,8 @@ def main():
         gen_blocks(pp, out)
     if want("full"):
         gen_full_model(pp, out)
+    if want("markers"):
+        gen_marker_rays(e3, r3, out)
     print("wrote", sorted(p.name for p in out.iterdir()))
 
 
