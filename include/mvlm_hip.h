@@ -105,6 +105,15 @@ int mvlm_cnn_maxima(mvlm_ctx* ctx, const float* images_dev, int n_views, const i
  * (what paulsenpredictor.py:187-212 accumulates); used by tests and "moment" mode. */
 int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
                       float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch);
+/* How the ~160 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
+ * shapes is captured as a hipGraph the second time it is seen and replayed afterwards; 0: always launch by
+ * launch.  concurrency 1 (default): for batches of <= 32 views the lower hourglass pyramid runs on a second
+ * stream beside the 128x128 / 64x64 skip blocks; 0: one stream.  Results are identical in every mode.
+ * mvlm_cnn_execution_stats reports how many passes ran eagerly / were captured / replayed, and how many
+ * captures failed (those passes ran eagerly instead). */
+int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency);
+int mvlm_cnn_execution_stats(mvlm_ctx* ctx, int64_t* eager_runs, int64_t* graph_captures, int64_t* graph_replays,
+                             int64_t* graph_failures);
 /* per-kernel timing of the last mvlm_cnn_* call when profiling is on: fills up to
  * `cap` records of {slot, kernel_variant, flops, ms}; returns the record count. */
 int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled);
@@ -124,6 +133,12 @@ int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, in
                 int ksize, const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
                 const float* post_scale_host, const float* post_shift_host, const float* r_dev, int upsample_in,
                 float* y_dev);
+
+/* kernel-variant timing for tools/tune_conv.py: `iters` launches of one layer shape on zero data with kernel
+ * variant `variant` (< 0: the dispatcher's choice, reported in *variant_used); flags: 1 pre-BN+ReLU, 2 residual
+ * add + raw copy, 4 bias, 8 post-BN+ReLU.  Fails for shapes the variant cannot serve. */
+int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int ksize, int size, int flags, int variant, int iters,
+                    float* ms_per_launch, int* variant_used);
 
 /* ---- rays + consensus (replaces estimator3d.py:31-90, :92-183, utils3d.py:99-124) - */
 /* maxima_dev f32[NL,N,3], rot_dev f64[N,9] -> starts_dev, ends_dev f64[NL,N,3] */

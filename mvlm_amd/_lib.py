@@ -47,12 +47,17 @@ SIGNATURES = {
                                   C.c_int]),
     "mvlm_cnn_heatmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.c_int]),
+    "mvlm_cnn_set_execution": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mvlm_cnn_execution_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64)]),
     "mvlm_cnn_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_cnn_get_profile": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_float_p, C.c_int]),
     "mvlm_conv_variant_name": (C.c_char_p, [C.c_int]),
     "mvlm_heatmap_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mvlm_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int,
                               c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvlm_conv_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  c_float_p, C.POINTER(C.c_int)]),
     "mvlm_estimate_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p]),
     "mvlm_consensus_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,

@@ -53,6 +53,12 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
         if (e) hipEventDestroy(e);
     for (auto e : ctx->render_events)
         if (e) hipEventDestroy(e);
+    for (auto e : ctx->cnn.sync_events)
+        if (e) hipEventDestroy(e);
+    for (auto& g : ctx->cnn.graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    if (ctx->cnn.side_stream) hipStreamDestroy(ctx->cnn.side_stream);
+    if (ctx->cnn.capture_stream) hipStreamDestroy(ctx->cnn.capture_stream);
     delete ctx;
 }
 
@@ -208,4 +214,80 @@ extern "C" int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin
     if (mvlm_launch_conv(ctx, a, nullptr)) return 1;
     MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+// ---- kernel-variant timing (tools/tune_conv.py): one layer shape, dummy data, a forced variant ----------
+// Times `iters` launches of one convolution with HIP events on the ctx stream.  flags: 1 = pre-BN+ReLU on the
+// input, 2 = residual add + raw copy (a residual block's conv1 / conv2), 4 = bias, 8 = post-BN+ReLU.
+// variant -1: the dispatcher's own choice, -2: its rules without the tuned table (returned in *variant_used).
+// Shapes a variant cannot serve fail.
+extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int ksize, int size, int flags, int variant,
+                               int iters, float* ms_per_launch, int* variant_used) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, batch > 0 && cin > 0 && cout > 0 && size > 0 && iters > 0 && ms_per_launch, "conv_bench: bad arguments");
+    MVLM_REQUIRE(ctx, ksize == 1 || ksize == 3, "conv_bench: kernel size must be 1 or 3");
+    const int cin_pad = (ksize == 1 ? (cin + 7) / 8 * 8 : (cin + 3) / 4 * 4), taps = ksize * ksize;
+    const bool plain = (flags & 4) && !(flags & (1 | 2 | 8));
+    const int cout_pad = (plain && (cout + 15) / 16 * 16 == 80) ? 80 : (cout + 31) / 32 * 32;
+    const size_t px = size_t(batch) * size * size;
+    const size_t n_w = size_t(taps) * cin_pad * cout_pad, n_vec = size_t(cin_pad) * 2 + size_t(cout_pad) * 3;
+    const size_t n_x = px * cin, n_y = px * cout;
+    const size_t total = n_w + n_vec + n_x + 3 * n_y + 64;
+    auto* base = static_cast<float*>(ctx->get_scratch("conv_bench", total * sizeof(float)));
+    MVLM_REQUIRE(ctx, base, "conv_bench: scratch allocation failed");
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(base, 0, total * sizeof(float), ctx->stream));
+    float* w = base;
+    float* vec = w + n_w;
+    float* x = vec + (n_vec + 3) / 4 * 4;
+    float* y = x + (n_x + 3) / 4 * 4;
+    float* raw = y + (n_y + 3) / 4 * 4;
+    float* res = raw + (n_y + 3) / 4 * 4;
+    ConvArgs a;
+    a.in = x;
+    a.in_ctot = cin;
+    a.cin = cin;
+    a.cin_pad = cin_pad;
+    a.B = batch;
+    a.H = a.W = size;
+    a.w = w;
+    a.cout = cout;
+    a.cout_pad = cout_pad;
+    a.ksize = ksize;
+    if (flags & 1) {
+        a.pre_scale = vec;
+        a.pre_shift = vec + cin_pad;
+    }
+    if (flags & 4) a.bias = vec + 2 * cin_pad;
+    if (flags & 8) {
+        a.post_scale = vec + 2 * cin_pad + cout_pad;
+        a.post_shift = vec + 2 * cin_pad + 2 * cout_pad;
+    }
+    if (flags & 2) {
+        a.res1 = res;
+        a.res1_ctot = cout;
+        a.out_raw = raw;
+        a.raw_ctot = cout;
+    }
+    a.out = y;
+    a.out_ctot = cout;
+    const int saved = ctx->conv_force_variant;
+    ctx->conv_force_variant = variant >= 0 ? variant : (variant == -2 ? -2 : -1);
+    int used = -1;
+    int rc = mvlm_launch_conv(ctx, a, &used);  // warm-up (also sets the launch attributes)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = ctx->fail("conv_bench: hipEventCreate failed");
+    if (!rc) {
+        hipEventRecord(e0, ctx->stream);
+        for (int i = 0; i < iters && !rc; ++i) rc = mvlm_launch_conv(ctx, a, nullptr);
+        hipEventRecord(e1, ctx->stream);
+        if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = ctx->fail("conv_bench: kernel failed");
+        float ms = 0.f;
+        if (!rc) hipEventElapsedTime(&ms, e0, e1);
+        *ms_per_launch = ms / iters;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    ctx->conv_force_variant = saved;
+    if (variant_used) *variant_used = used;
+    return rc;
 }

@@ -21,6 +21,10 @@
 
 namespace {
 
+// the hourglass runs its lower pyramid beside the skip blocks when a 32x32 level holds at most this many
+// pixels over the whole batch (= 32 views)
+constexpr long CONCURRENT_MAX_PIXELS_32 = 32l * 32 * 32;
+
 struct Tensor {
     float* p = nullptr;
     int C = 0, S = 0;
@@ -30,6 +34,8 @@ struct Tensor {
 struct Block {
     size_t off, size;
     bool free;
+    int arena;      // 0: main stream, 1: side stream - a block is only ever reused by kernels of its own arena's stream
+    bool deferred;  // released while the streams ran apart: becomes free at the join
 };
 
 struct Exec {
@@ -42,6 +48,8 @@ struct Exec {
     size_t cursor = 0, high = 0;
     std::vector<Block> blocks;
     int rc = 0;
+    int arena = 0;        // arena new tensors come from = stream the next launches go to
+    bool forked = false;
 
     Exec(mvlm_ctx* c, int batch, void* w, size_t wb, bool d) : ctx(c), st(c->cnn), B(batch), ws((char*)w), ws_bytes(wb), dry(d) {}
 
@@ -52,13 +60,13 @@ struct Exec {
         t.S = S;
         t.elems = bytes / 4;
         for (auto& b : blocks)
-            if (b.free && b.size == bytes) {
+            if (b.free && b.size == bytes && b.arena == arena) {
                 b.free = false;
                 t.off = b.off;
                 t.p = dry ? nullptr : reinterpret_cast<float*>(ws + b.off);
                 return t;
             }
-        blocks.push_back({cursor, bytes, false});
+        blocks.push_back({cursor, bytes, false, arena, false});
         t.off = cursor;
         cursor += bytes;
         if (cursor > high) high = cursor;
@@ -71,12 +79,66 @@ struct Exec {
         return t;
     }
     Tensor alloc(int C, int S) { return alloc_raw(size_t(B) * C * S * S * 4, C, S); }
+    // Stream order makes "release, then reuse" safe within one stream.  While the two streams run apart
+    // a main-arena tensor may still be read by kernels of the other stream (the branch's inputs), so
+    // main-arena releases wait for the join; side-arena tensors are only touched by the side stream
+    // until the join and can be recycled there at once.
     void release(const Tensor& t) {
         for (auto& b : blocks)
-            if (b.off == t.off && !b.free) {
-                b.free = true;
+            if (b.off == t.off && !b.free && !b.deferred) {
+                if (forked && b.arena == 0)
+                    b.deferred = true;
+                else
+                    b.free = true;
                 return;
             }
+    }
+
+    // ---- two-stream execution: fork() .. side() .. main() .. join() ---------------------------
+    hipEvent_t next_event() {
+        if (st.sync_cursor >= st.sync_events.size()) st.sync_events.resize(st.sync_cursor + 1, nullptr);
+        hipEvent_t& e = st.sync_events[st.sync_cursor++];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            rc = ctx->fail("cnn: hipEventCreate failed");
+            return nullptr;
+        }
+        return e;
+    }
+    // everything enqueued on the main stream so far happens before what the side stream gets from now on
+    void fork() {
+        forked = true;
+        if (dry || rc) return;
+        if (!st.side_stream && hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = ctx->fail("cnn: hipStreamCreate failed");
+            return;
+        }
+        hipEvent_t e = next_event();
+        if (rc) return;
+        if (hipEventRecord(e, ctx->stream) != hipSuccess || hipStreamWaitEvent(st.side_stream, e, 0) != hipSuccess)
+            rc = ctx->fail("cnn: fork of the side stream failed");
+    }
+    void side() {
+        arena = 1;
+        if (!dry) ctx->launch_stream = st.side_stream;
+    }
+    void main() {
+        arena = 0;
+        ctx->launch_stream = nullptr;
+    }
+    // the main stream continues after everything the side stream was given
+    void join() {
+        main();
+        forked = false;
+        for (auto& b : blocks)
+            if (b.deferred) {
+                b.deferred = false;
+                b.free = true;
+            }
+        if (dry || rc) return;
+        hipEvent_t e = next_event();
+        if (rc) return;
+        if (hipEventRecord(e, st.side_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, e, 0) != hipSuccess)
+            rc = ctx->fail("cnn: join of the side stream failed");
     }
 
     const int32_t* d(int slot) const { return &st.desc[size_t(slot) * MVLM_CONV_DESC_INTS]; }
@@ -118,11 +180,11 @@ struct Exec {
             e0 = st.event_pool[st.event_cursor];
             e1 = st.event_pool[st.event_cursor + 1];
             st.event_cursor += 2;
-            hipEventRecord(e0, ctx->stream);
+            hipEventRecord(e0, ctx->cur_stream());
         }
         if (mvlm_launch_conv(ctx, a, &variant)) return rc = 1;
         if (st.profiling) {
-            hipEventRecord(e1, ctx->stream);
+            hipEventRecord(e1, ctx->cur_stream());
             const double flops = 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(S) * S * B;
             st.prof.push_back({slot, variant, flops, e0, e1});
         }
@@ -226,11 +288,23 @@ struct Exec {
     // x_pooled = max_pool2d(x) (the producer of x emits it from its epilogue where it can).
     Tensor hourglass(int rb0, const Tensor& x, const Tensor& x_pooled) {
         auto R = [&](int i) { return rb0 + i - 1; };
-        Tensor up1 = rb(R(1), x, nullptr);
+        // Small batches: the 32x32 .. 4x4 levels are a chain of ~60 short, latency-bound launches on few
+        // workgroups.  They only depend on low1's pooled copy, and the 128x128 / 64x64 skip blocks (up1, up11)
+        // do not depend on them, so the chain runs on the side stream beside those big launches.  Large
+        // batches fill the chip with every launch; there the order stays sequential.
+        const bool concurrent = st.concurrency != 0 && long(B) * 32 * 32 <= CONCURRENT_MAX_PIXELS_32;
         Tensor lowt11, lowt12, lowt13, lowt14;
         Tensor low1 = rb(R(2), x_pooled, nullptr, &lowt11);
-        Tensor up11 = rb(R(3), low1, nullptr);
-        release(low1);
+        if (concurrent) {
+            fork();
+            side();
+        }
+        Tensor up1, up11;
+        if (!concurrent) {
+            up1 = rb(R(1), x, nullptr);
+            up11 = rb(R(3), low1, nullptr);
+            release(low1);
+        }
         Tensor low11 = rb(R(4), lowt11, nullptr, &lowt12);
         release(lowt11);
         Tensor up12 = rb(R(5), low11, nullptr);
@@ -259,6 +333,13 @@ struct Exec {
         release(low22);
         Tensor low23 = rb(R(17), up12, nullptr);
         release(up12);
+        if (concurrent) {
+            main();
+            up11 = rb(R(3), low1, nullptr);
+            release(low1);
+            up1 = rb(R(1), x, nullptr);
+            join();
+        }
         rb(R(18), low23, &up11);  // add4
         release(low23);
         Tensor low24 = rb(R(19), up11, nullptr);
@@ -397,6 +478,116 @@ struct Exec {
     }
 };
 
+// One batch of views through the network.  Eager: the ~160 launches are enqueued one by one (two streams
+// for small batches).  Replay: the same sequence, captured once per (buffers, shapes) as a hipGraph with
+// the side stream's work as a parallel branch, is launched with one call - at small batches the host
+// otherwise spends as long enqueueing as the GPU spends computing.  A key is captured the second time it is
+// seen (the first, eager pass also performs the one-time launch-attribute set-up, which must not happen
+// inside a capture).  Profiling (per-launch events) always runs eagerly.
+int run_batch(mvlm_ctx* ctx, const float* img, int nb, const int* sel4, float* maxima, int view0, int n_total,
+              float* heat, void* ws, size_t ws_bytes) {
+    CnnState& st = ctx->cnn;
+    auto eager = [&]() {
+        st.sync_cursor = 0;
+        Exec ex(ctx, nb, ws, ws_bytes, false);
+        const int rc = ex.forward(img, sel4, maxima, view0, n_total, heat);
+        ctx->launch_stream = nullptr;
+        ++st.eager_runs;
+        return rc;
+    };
+    if (!st.graph_mode || st.profiling) return eager();
+    const void* out = heat ? static_cast<const void*>(heat) : static_cast<const void*>(maxima);
+    CnnGraphEntry* ent = nullptr;
+    for (auto& g : st.graphs)
+        if (g.images == img && g.out == out && g.ws == ws && g.ws_bytes == ws_bytes && g.nb == nb && g.view0 == view0 &&
+            g.n_total == n_total && g.heat == (heat ? 1 : 0) && g.sel4[0] == sel4[0] && g.sel4[1] == sel4[1] &&
+            g.sel4[2] == sel4[2] && g.sel4[3] == sel4[3]) {
+            ent = &g;
+            break;
+        }
+    if (!ent) {
+        constexpr size_t MAX_GRAPHS = 16;
+        if (st.graphs.size() >= MAX_GRAPHS) {  // drop the oldest entry
+            if (st.graphs.front().exec) hipGraphExecDestroy(st.graphs.front().exec);
+            st.graphs.erase(st.graphs.begin());
+        }
+        CnnGraphEntry g;
+        g.images = img;
+        g.out = out;
+        g.ws = ws;
+        g.ws_bytes = ws_bytes;
+        g.nb = nb;
+        g.view0 = view0;
+        g.n_total = n_total;
+        g.heat = heat ? 1 : 0;
+        for (int k = 0; k < 4; ++k) g.sel4[k] = sel4[k];
+        st.graphs.push_back(g);
+        ent = &st.graphs.back();
+    }
+    ++ent->uses;
+    if (ent->exec) {
+        MVLM_CHECK_HIP(ctx, hipGraphLaunch(ent->exec, ctx->stream));
+        ++st.graph_replays;
+        return 0;
+    }
+    if (ent->uses < 2) return eager();
+    // capture.  The caller's stream may be the legacy null stream (torch's default), which cannot be captured:
+    // the pass is recorded on a stream of our own and the resulting graph is launched on the caller's.
+    auto note = [&](const char* what, hipError_t e) {
+        if (st.graph_failures++ == 0)
+            fprintf(stderr, "mvlm_hip: %s failed (%s); this pass runs launch by launch\n", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+    };
+    if (!st.capture_stream) {
+        const hipError_t e = hipStreamCreateWithFlags(&st.capture_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            st.capture_stream = nullptr;
+            note("hipStreamCreate (capture stream)", e);
+            return eager();
+        }
+    }
+    st.sync_cursor = 0;
+    hipStream_t user_stream = ctx->stream;
+    hipError_t e_begin = hipStreamBeginCapture(st.capture_stream, hipStreamCaptureModeThreadLocal);
+    if (e_begin != hipSuccess) {
+        note("hipStreamBeginCapture", e_begin);
+        return eager();
+    }
+    int rc;
+    ctx->stream = st.capture_stream;
+    {
+        Exec ex(ctx, nb, ws, ws_bytes, false);
+        rc = ex.forward(img, sel4, maxima, view0, n_total, heat);
+        ctx->launch_stream = nullptr;
+    }
+    ctx->stream = user_stream;
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(st.capture_stream, &graph);
+    if (rc) {  // the executor's own error (message already set); nothing was enqueued
+        if (graph) hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e_end != hipSuccess || !graph) {
+        note("hipStreamEndCapture", e_end);
+        if (graph) hipGraphDestroy(graph);
+        ent->uses = -1000000;  // do not try this key again
+        return eager();
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e_inst != hipSuccess || !exec) {
+        note("hipGraphInstantiate", e_inst);
+        ent->uses = -1000000;
+        return eager();
+    }
+    ent->exec = exec;
+    ++st.graph_captures;
+    MVLM_CHECK_HIP(ctx, hipGraphLaunch(ent->exec, ctx->stream));
+    ++st.graph_replays;
+    return 0;
+}
+
 int run_cnn(mvlm_ctx* ctx, const float* images, int n_views, const int32_t* chan_sel, float* maxima, float* heat,
             void* ws, size_t ws_bytes, int batch) {
     CnnState& st = ctx->cnn;
@@ -413,9 +604,9 @@ int run_cnn(mvlm_ctx* ctx, const float* images, int n_views, const int32_t* chan
     const size_t img_elems = size_t(MVLM_IMAGE_SIZE) * MVLM_IMAGE_SIZE;
     for (int v0 = 0; v0 < n_views; v0 += batch) {
         const int nb = (n_views - v0) < batch ? (n_views - v0) : batch;
-        Exec ex(ctx, nb, ws, ws_bytes, false);
         float* h = heat ? heat + size_t(v0) * st.n_landmarks * img_elems : nullptr;
-        if (ex.forward(images + size_t(v0) * img_elems * 4, sel4, maxima, v0, n_views, h)) return 1;
+        const float* img = images + size_t(v0) * img_elems * 4;
+        if (run_batch(ctx, img, nb, sel4, maxima, v0, n_views, h, ws, ws_bytes)) return 1;
     }
     return 0;
 }
@@ -435,6 +626,9 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
         st.blob = nullptr;
     }
     st.loaded = false;
+    for (auto& g : st.graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);  // captured launches point into the old weight blob
+    st.graphs.clear();
     st.desc.assign(desc_host, desc_host + size_t(n_slots) * MVLM_CONV_DESC_INTS);
     // validate every offset before anything is launched with it
     for (int s = 0; s < n_slots; ++s) {
@@ -481,6 +675,32 @@ extern "C" int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_v
     MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, heat_dev && chan_sel_host, "cnn_heatmaps: null output / selector");
     return run_cnn(ctx, images_dev, n_views, chan_sel_host, nullptr, heat_dev, workspace_dev, workspace_bytes, batch);
+}
+
+extern "C" int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, (graph_mode == 0 || graph_mode == 1) && (concurrency == 0 || concurrency == 1),
+                 "cnn_set_execution: flags must be 0 or 1");
+    CnnState& st = ctx->cnn;
+    if (concurrency != st.concurrency) {  // captured graphs encode the launch order
+        for (auto& g : st.graphs)
+            if (g.exec) hipGraphExecDestroy(g.exec);
+        st.graphs.clear();
+    }
+    st.graph_mode = graph_mode;
+    st.concurrency = concurrency;
+    return 0;
+}
+
+extern "C" int mvlm_cnn_execution_stats(mvlm_ctx* ctx, int64_t* eager_runs, int64_t* graph_captures,
+                                        int64_t* graph_replays, int64_t* graph_failures) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const CnnState& st = ctx->cnn;
+    if (eager_runs) *eager_runs = st.eager_runs;
+    if (graph_captures) *graph_captures = st.graph_captures;
+    if (graph_replays) *graph_replays = st.graph_replays;
+    if (graph_failures) *graph_failures = st.graph_failures;
+    return 0;
 }
 
 extern "C" int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled) {

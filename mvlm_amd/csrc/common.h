@@ -90,6 +90,18 @@ struct ConvProfileRec {
     hipEvent_t e0, e1;
 };
 
+// one captured forward pass (hipGraph) of the network for a fixed set of buffers and shapes
+struct CnnGraphEntry {
+    const void* images = nullptr;
+    const void* out = nullptr;   // maxima or heatmap pointer
+    const void* ws = nullptr;
+    size_t ws_bytes = 0;
+    int nb = 0, view0 = 0, n_total = 0, heat = 0;
+    int sel4[4] = {0, 0, 0, 0};
+    int uses = 0;                // calls seen with this key; the graph is captured on the second one
+    hipGraphExec_t exec = nullptr;
+};
+
 struct CnnState {
     bool loaded = false;
     int n_landmarks = 0, in_channels = 0;
@@ -99,6 +111,15 @@ struct CnnState {
     std::vector<ConvProfileRec> prof;
     std::vector<hipEvent_t> event_pool;
     size_t event_cursor = 0;
+    // second stream + fork / join events of the executor (created on first use), captured graphs
+    hipStream_t side_stream = nullptr;
+    hipStream_t capture_stream = nullptr;  // passes are recorded here (the caller's stream may be the null stream)
+    std::vector<hipEvent_t> sync_events;
+    size_t sync_cursor = 0;
+    int graph_mode = 1;            // 0: always eager, 1: replay captured graphs when not profiling
+    int concurrency = 1;           // 0: one stream, 1: lower hourglass pyramid on the side stream (small batches)
+    std::vector<CnnGraphEntry> graphs;
+    long graph_replays = 0, graph_captures = 0, eager_runs = 0, graph_failures = 0;
 };
 
 struct mvlm_mesh {
@@ -118,11 +139,16 @@ struct RenderProfileRec {
 struct mvlm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // where the network executor's launchers enqueue right now: null = `stream`; the executor points it at
+    // its side stream while it issues the branch of the graph that runs beside the main one (cnn_graph.hip)
+    hipStream_t launch_stream = nullptr;
+    hipStream_t cur_stream() const { return launch_stream ? launch_stream : stream; }
     std::mutex mu;
     std::string err;
     CnnState cnn;
     // grow-only internal scratch (raster bins, transformed vertices, small staging)
     std::map<std::string, std::pair<void*, size_t>> scratch;
+    int conv_force_variant = -1;            // >= 0: mvlm_conv_bench times exactly this kernel variant
     unsigned long long conv_attr_mask = 0;  // conv variants whose launch attributes are set on this ctx's device
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render

@@ -842,7 +842,9 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
     const int tiles_x = a.W / C::TW, tiles_y = a.H / C::TRI;
     const int tiles_b = (a.B + C::NIMG - 1) / C::NIMG;
     const int cout_tiles = a.cout_pad / C::COUT_T;
+    MVLM_REQUIRE(ctx, a.ksize == C::KS, "conv: kernel variant built for another kernel size");
     MVLM_REQUIRE(ctx, a.W % C::TW == 0 && a.H % C::TRI == 0, "conv: spatial size not a multiple of the tile");
+    MVLM_REQUIRE(ctx, !C::SPLITK || a.cin_pad % 32 == 0, "conv: split-K tiles need 32-channel chunks");
     MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
     MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
     MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
@@ -869,13 +871,13 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
     }
     if (a.amax_val) {
         if constexpr (C::HAS_AMAX) {
-            hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream,
+            hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(),
                                a, tiles_x, tiles_y, cout_tiles);
         } else {
             return ctx->fail("conv: fused argmax is only built for the 8x32-pixel tile variants");
         }
     } else {
-        hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->stream, a,
+        hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
                            tiles_x, tiles_y, cout_tiles);
     }
     MVLM_CHECK_HIP(ctx, hipGetLastError());

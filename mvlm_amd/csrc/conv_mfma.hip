@@ -35,6 +35,8 @@
 #include "common.h"
 #include "conv_kernel.h"   // Cfg<> (tile geometry) for the compile-time queries below; kernels are not instantiated here
 #include "conv_variants.h"
+#include "conv_tuned.h"
+#include <algorithm>
 
 // one launcher per variant, defined in conv_inst_g*.hip
 #define X(id, name, ...) int mvlm_conv_launch_##id(mvlm_ctx* ctx, const ConvArgs& a);
@@ -46,7 +48,7 @@ namespace {
 // level holds at most this many pixels in total -> latency-bound launch, split-K tiles
 constexpr long SPLITK_MAX_PIXELS = 8192;
 
-int pick_variant(const ConvArgs& a) {
+int pick_variant_rules(const ConvArgs& a) {
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
     if (a.ksize == 2) return (a.W >= 32 && a.H % 8 == 0) ? (a.cout_pad == 96 ? 11 : a.cout_pad == 80 ? 17 : -1) : -1;
     if (a.cout_pad == 80) return (a.W >= 32 && a.H % 8 == 0) ? 16 : -1;  // 64 rows + one 16-row strip
@@ -73,6 +75,26 @@ int pick_variant(const ConvArgs& a) {
     if (a.W == 8) return sk ? 13 : (a.cin_pad % 16 == 0 ? 6 : -1);
     if (a.W == 4) return sk ? 14 : (a.cin_pad % 16 == 0 ? 7 : -1);
     return -1;
+}
+
+// Measured choice first (conv_tuned.h: the network's own layer shapes at the tuned device batches, plain layers
+// only - the fused argmax / upsampling launches have one kernel that can serve them), the rules otherwise.
+int pick_variant(const ConvArgs& a, bool rules_only = false) {
+    const int by_rule = pick_variant_rules(a);
+    if (rules_only || MVLM_CONV_TUNED_N == 0 || a.amax_val || a.up_in || a.up_out == 2 || a.ksize == 2 || a.H != a.W) return by_rule;
+    const ConvTuned key = {short(a.ksize), short(a.cin_pad), short(a.cout_pad), short(a.H), short(a.B > 32767 ? 32767 : a.B), 0};
+    auto less = [](const ConvTuned& x, const ConvTuned& y) {
+        if (x.ksize != y.ksize) return x.ksize < y.ksize;
+        if (x.cin_pad != y.cin_pad) return x.cin_pad < y.cin_pad;
+        if (x.cout_pad != y.cout_pad) return x.cout_pad < y.cout_pad;
+        if (x.size != y.size) return x.size < y.size;
+        return x.batch < y.batch;
+    };
+    const ConvTuned* end = MVLM_CONV_TUNED + MVLM_CONV_TUNED_N;
+    const ConvTuned* it = std::lower_bound(MVLM_CONV_TUNED, end, key, less);  // smallest tuned batch >= B of this shape
+    if (it == end || it->ksize != key.ksize || it->cin_pad != key.cin_pad || it->cout_pad != key.cout_pad || it->size != key.size)
+        return by_rule;
+    return it->variant;
 }
 
 }  // namespace
@@ -120,7 +142,8 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     MVLM_REQUIRE(ctx, !a.res2 || px * a.res2_ctot < lim, "conv: residual exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, !a.out || px * a.out_ctot * (a.up_out ? 4 : 1) < lim, "conv: output exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, a.up_out != 1 || px * a.skip_ctot * 4 < lim, "conv: skip tensor exceeds 32-bit element offsets");
-    const int v = pick_variant(a);
+    // conv_force_variant (mvlm_conv_bench only): >= 0 that variant, -2 the rules without the tuned table
+    const int v = ctx->conv_force_variant >= 0 ? ctx->conv_force_variant : pick_variant(a, ctx->conv_force_variant == -2);
     MVLM_REQUIRE(ctx, v >= 0, "conv: no kernel variant for this shape");
     MVLM_REQUIRE(ctx, !a.pool_out || mvlm_conv_can_pool(a), "conv: this shape's kernel variant cannot emit the pooled tensor");
     MVLM_REQUIRE(ctx, !a.pool_out || px / 4 * a.pool_ctot < lim, "conv: pooled output exceeds 32-bit element offsets");

@@ -172,7 +172,7 @@ __global__ void heatmap_maxima_kernel(const float* __restrict__ heat, int n_view
 int mvlm_launch_pack_input(mvlm_ctx* ctx, const float* images, int n, const int* sel4, int c, float* out) {
     const int hw = MVLM_IMAGE_SIZE * MVLM_IMAGE_SIZE;
     const int total = n * hw;
-    hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->cur_stream(),
                        reinterpret_cast<const float4*>(images), total, hw, make_int4(sel4[0], sel4[1], sel4[2], sel4[3]),
                        c, out);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
@@ -183,7 +183,7 @@ int mvlm_launch_maxpool2(mvlm_ctx* ctx, const float* in, int planes, int H, int 
     MVLM_REQUIRE(ctx, W % 4 == 0 && H % 2 == 0, "maxpool: size must be a multiple of 4");
     const long n_out = long(planes) * (H / 2) * (W / 2);
     const long threads = n_out / 2;
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, in, n_out,
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->cur_stream(), in, n_out,
                        W / 2, out);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
@@ -191,7 +191,7 @@ int mvlm_launch_maxpool2(mvlm_ctx* ctx, const float* in, int planes, int H, int 
 
 int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int n_img, int view0, int n_views_total,
                            int nl, int parts, int size, float* maxima) {
-    hipLaunchKernelGGL(amax_final_kernel, dim3(n_img * nl), dim3(256), 0, ctx->stream, val, idx, nl, parts, size, view0,
+    hipLaunchKernelGGL(amax_final_kernel, dim3(n_img * nl), dim3(256), 0, ctx->cur_stream(), val, idx, nl, parts, size, view0,
                        n_views_total, maxima);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;

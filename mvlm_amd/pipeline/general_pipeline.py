@@ -86,6 +86,7 @@ class Pipeline(abc.ABC):
         self._timer = StageTimer(self.timings, self._say)
         self.last_error: float | None = None
         self._rays = None  # (mesh, starts, ends) of the current call when visualize_rays is set
+        self._buffers: dict = {}
         # optional "pre-align" block of a Deep-MVLM config (mvlm_amd/utils/prealign.py); the
         # reference's live pipeline has none (it renders the mesh as-is)
         self.pre_align: dict | None = None
@@ -105,6 +106,16 @@ class Pipeline(abc.ABC):
         if self.predictor_2d is None:
             raise ValueError("Predictor2D is not initialized.")
         return self.predictor_2d.get_lm_count()
+
+    def _buffer(self, name: str, shape: tuple):
+        """A float32 device tensor of this shape that lives as long as the pipeline (one per name)."""
+        import torch
+
+        buf = self._buffers.get(name)
+        if buf is None or tuple(buf.shape) != tuple(shape):
+            buf = torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", self.device))
+            self._buffers[name] = buf
+        return buf
 
     def _say(self, *a):
         if self.verbose:
@@ -186,14 +197,21 @@ class Pipeline(abc.ABC):
         rot = view_rotations(transform_stack)  # once per call: renderer and estimator share it
         tm = self._timer
         with tm.stage("render"):
-            images = r3.render_device(mesh, transform_stack[lo:hi], rot=rot[lo:hi]) if hi > lo else None
+            # one image stack / maxima buffer per view count, reused from call to call: stable addresses let the
+            # predictor replay its captured launch graph instead of re-enqueueing ~160 kernels per mesh
+            images = None
+            if hi > lo:
+                images = r3.render_device(mesh, transform_stack[lo:hi], rot=rot[lo:hi],
+                                          out=self._buffer("images", (hi - lo, 256, 256, 4)))
             if self.verbose:
                 torch.cuda.synchronize()
         if self.render_image_stack and images is not None:
             self.visualize_image_stack(images.cpu().numpy(), mesh.path or Path("mesh.obj"), first_index=lo)
 
         with tm.stage("prediction"):
-            if images is not None:
+            if images is not None and isinstance(p2, HipPaulsenModel):
+                maxima = p2.predict_device(images, out=self._buffer("maxima", (p2.get_lm_count(), hi - lo, 3)))
+            elif images is not None:
                 maxima = p2.predict_device(images)
             else:
                 maxima = torch.empty((p2.get_lm_count(), 0, 3), dtype=torch.float32,

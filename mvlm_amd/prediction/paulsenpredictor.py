@@ -125,8 +125,10 @@ class HipPaulsenModel(Predictor2D):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", self.ctx.device))
         return self._workspace
 
-    def predict_device(self, image_stack_dev):
-        """torch f32 [N,256,256,4] on this GPU -> maxima torch f32 [NL,N,3] on the GPU."""
+    def predict_device(self, image_stack_dev, out=None):
+        """torch f32 [N,256,256,4] on this GPU -> maxima torch f32 [NL,N,3] on the GPU (written into ``out``
+        when given).  A pass over the same buffers is captured as a hipGraph on its second use and replayed
+        afterwards (mvlm_cnn_set_execution), so callers in a loop should hand over stable buffers."""
         import torch
 
         dev = torch.device("cuda", self.ctx.device)
@@ -138,7 +140,12 @@ class HipPaulsenModel(Predictor2D):
         batch = self._batch_for(n)
         ws = self._get_workspace(batch)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        maxima = torch.empty((nl, n, 3), dtype=torch.float32, device=dev)
+        if out is None:
+            maxima = torch.empty((nl, n, 3), dtype=torch.float32, device=dev)
+        else:
+            maxima = out
+            if tuple(out.shape) != (nl, n, 3) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise ValueError("predict_device: out must be a contiguous float32 [NL,N,3] tensor")
         if self.selection_method == "simple":
             self.ctx.check(self.ctx.lib.mvlm_cnn_maxima(
                 self.ctx.handle, C.c_void_p(x.data_ptr()), n, _lib.as_ptr(self.chan_sel, C.c_int32),
@@ -155,6 +162,16 @@ class HipPaulsenModel(Predictor2D):
                                                                 1, C.c_void_p(part.data_ptr())))
                 maxima[:, s:s + nb] = part
         return maxima
+
+    def set_execution(self, graphs: bool = True, concurrency: bool = True):
+        """How the forward pass is issued (mvlm_cnn_set_execution): replayed hipGraphs / launch by launch, and
+        whether small batches run the lower hourglass pyramid on a second stream.  Results do not depend on it."""
+        self.ctx.check(self.ctx.lib.mvlm_cnn_set_execution(self.ctx.handle, int(bool(graphs)), int(bool(concurrency))))
+
+    def execution_stats(self) -> dict:
+        v = [C.c_int64() for _ in range(4)]
+        self.ctx.check(self.ctx.lib.mvlm_cnn_execution_stats(self.ctx.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("eager_runs", "graph_captures", "graph_replays", "graph_failures"), (int(x.value) for x in v)))
 
     def heatmaps_device(self, image_stack_dev):
         """Final-stage heatmaps torch f32 [N,NL,256,256] (tests / diagnostics)."""

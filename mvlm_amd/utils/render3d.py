@@ -131,14 +131,18 @@ class HipRenderer3D:
         return self.random_transform(size=self.n_views)
 
     # ---- rendering --------------------------------------------------------------------
-    def render_device(self, mesh: Mesh, transform_stack: np.ndarray, rot: np.ndarray | None = None):
+    def render_device(self, mesh: Mesh, transform_stack: np.ndarray, rot: np.ndarray | None = None, out=None):
         """Poses -> torch.float32 [N,256,256,4] on the device (RGB + depth, /255, flipped).
-        Only enqueues work; ``check()`` reports a deferred failure after the caller's sync."""
+        Only enqueues work; ``check()`` reports a deferred failure after the caller's sync.
+        ``out``: an existing stack of that shape to render into (the pipeline reuses one buffer per view count)."""
         import torch
 
         n = int(transform_stack.shape[0])
         dev = torch.device("cuda", self.ctx.device)
-        out = torch.empty((n, 256, 256, 4), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((n, 256, 256, 4), dtype=torch.float32, device=dev)
+        elif tuple(out.shape) != (n, 256, 256, 4) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("render_device: out must be a contiguous float32 [N,256,256,4] tensor on the renderer's GPU")
         rot = np.ascontiguousarray(view_rotations(transform_stack) if rot is None else rot, dtype=np.float64)
         handle = upload_mesh(self.ctx, mesh)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
