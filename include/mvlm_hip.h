@@ -60,6 +60,11 @@ int mvlm_obj_info(const mvlm_obj* obj, int64_t* n_verts, int64_t* n_tris, int* h
  * tris i32[T,3] */
 int mvlm_obj_copy(const mvlm_obj* obj, float* verts, float* uvs, int32_t* tris);
 void mvlm_obj_free(mvlm_obj* obj);
+/* The reference's legacy multi-format reader (Utils3D.multi_read_surface, utils3d.py:389-423) by file extension:
+ * .obj (as above), .ply (ASCII / binary), .stl (ASCII / binary, coincident points merged like vtkSTLReader),
+ * .vtk (legacy POLYDATA, ASCII / BINARY), .wrl (VRML 2.0 IndexedFaceSet, the last one of the file).  Fills the
+ * same handle; texture coordinates are kept where the format carries them per point / corner. */
+int mvlm_mesh_read(const char* path, mvlm_obj** out, char* err, int err_len);
 
 /* ---- mesh (replaces utils3d.py:10-85 obj_to_actor's upload half) ---------------- */
 /* verts f32[V,3], uvs f32[V,2] or NULL, tris i32[T,3], tex u8[H,W,3] (row 0 = top of

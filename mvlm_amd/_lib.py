@@ -30,6 +30,7 @@ SIGNATURES = {
     "mvlm_synchronize": (C.c_int, [C.c_void_p]),
     "mvlm_build_arch": (C.c_char_p, []),
     "mvlm_obj_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
+    "mvlm_mesh_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     "mvlm_obj_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "mvlm_obj_copy": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_int32_p]),
     "mvlm_obj_free": (None, [C.c_void_p]),

@@ -27,13 +27,7 @@
 #include <vector>
 
 #include "../../include/mvlm_hip.h"
-
-struct mvlm_obj {  // same layout as in obj_reader.hip (one definition per translation unit, identical)
-    std::vector<float> verts;
-    std::vector<float> uvs;
-    std::vector<int32_t> tris;
-    int64_t n_positions = 0;
-};
+#include "mesh_obj.h"
 
 namespace {
 
@@ -616,42 +610,132 @@ struct VrmlScan {
 int read_wrl(const std::vector<char>& data, mvlm_obj* o, std::string* msg) {
     if (data.size() < 5 || memcmp(data.data(), "#VRML", 5) != 0) { *msg = "not a VRML file"; return MVLM_OBJ_ERR_SYNTAX; }
     VrmlScan sc{data.data(), data.data() + data.size()};
+    sc.p += 5;
+    while (sc.p < sc.end && *sc.p != '\n') ++sc.p;  // rest of the "#VRML V2.0 utf8" line
     struct Set {
         std::vector<double> pts, tex, idx, tidx;
-        bool used = false;
     };
     Set cur, last;
+    bool have_last = false;
+    std::vector<std::string> stack;  // node types of the open braces
+    int set_depth = -1;
     std::string t, prev;
-    int depth = 0, set_depth = -1;
-    auto close = [&]() {
-        if (cur.used && !cur.pts.empty() && !cur.idx.empty()) last = cur;
-        cur = Set();
-        set_depth = -1;
-    };
     std::vector<double> tmp;
+    auto in_set = [&]() { return set_depth >= 0; };
     while (sc.next(&t)) {
         if (t == "{") {
-            ++depth;
-            if (prev == "IndexedFaceSet") {
-                if (set_depth >= 0) close();
-                set_depth = depth;
-                cur.used = true;
+            if (stack.size() > 256) { *msg = "VRML nesting too deep"; return MVLM_OBJ_ERR_SYNTAX; }
+            stack.push_back(prev);
+            if (prev == "IndexedFaceSet" && !in_set()) {
+                set_depth = int(stack.size());
+                cur = Set();
             }
         } else if (t == "}") {
-            if (depth == set_depth) close();
-            --depth;
-        } else if (set_depth >= 0) {
-            if (t == "point") {
-                if (!sc.numbers(&tmp)) { *msg = "bad VRML point list"; return MVLM_OBJ_ERR_SYNTAX; }
-                // the enclosing node decides: Coordinate -> points, TextureCoordinate -> texture coordinates
-                if (prev == "{" && false) {}
-                if (cur_node_is_tex) cur.tex = tmp; else cur.pts = tmp;
+            if (stack.empty()) { *msg = "unbalanced braces in VRML file"; return MVLM_OBJ_ERR_SYNTAX; }
+            if (int(stack.size()) == set_depth) {
+                if (!cur.pts.empty()) {
+                    last = cur;
+                    have_last = true;
+                }
+                set_depth = -1;
             }
+            stack.pop_back();
+        } else if (in_set() && (t == "point" || t == "coordIndex" || t == "texCoordIndex")) {
+            if (!sc.numbers(&tmp)) { *msg = "bad VRML number list"; return MVLM_OBJ_ERR_SYNTAX; }
+            if (t == "coordIndex") cur.idx = tmp;
+            else if (t == "texCoordIndex") cur.tidx = tmp;
+            else if (!stack.empty() && stack.back() == "Coordinate") cur.pts = tmp;
+            else if (!stack.empty() && stack.back() == "TextureCoordinate") cur.tex = tmp;
         }
         prev = t;
     }
-    (void)last;
+    if (!have_last) { *msg = "VRML file without an IndexedFaceSet"; return MVLM_OBJ_ERR_EMPTY; }
+    const long long n_pts = (long long)(last.pts.size() / 3), n_tex = (long long)(last.tex.size() / 2);
+    const bool per_corner_tex = n_tex > 0 && !last.tidx.empty() && last.tidx.size() == last.idx.size();
+    const bool per_point_tex = n_tex > 0 && !per_corner_tex && n_tex == n_pts;
+    // corners (point, texture coordinate) in order of first use, as the OBJ reader numbers them
+    std::unordered_map<uint64_t, int32_t> corner;
+    std::vector<long long> ids;
+    auto flush = [&]() {
+        if (ids.size() >= 3) fan(ids, &o->tris);
+        ids.clear();
+    };
+    for (size_t i = 0; i < last.idx.size(); ++i) {
+        const double dv = last.idx[i];
+        if (dv < 0) {
+            flush();
+            continue;
+        }
+        const long long v = (long long)dv;
+        if (v >= n_pts) { *msg = "VRML face references a point that does not exist"; return MVLM_OBJ_ERR_INDEX; }
+        long long tc = -1;
+        if (per_corner_tex) {
+            tc = (long long)last.tidx[i];
+            if (tc < 0 || tc >= n_tex) { *msg = "VRML face references a texture coordinate that does not exist"; return MVLM_OBJ_ERR_INDEX; }
+        } else if (per_point_tex) {
+            tc = v;
+        }
+        const uint64_t key = (uint64_t(uint32_t(v)) << 32) | uint64_t(uint32_t(int32_t(tc)));
+        auto it = corner.find(key);
+        int32_t id;
+        if (it == corner.end()) {
+            id = int32_t(o->verts.size() / 3);
+            corner.emplace(key, id);
+            for (int k = 0; k < 3; ++k) o->verts.push_back(float(last.pts[size_t(v) * 3 + size_t(k)]));
+            if (per_corner_tex || per_point_tex) {
+                o->uvs.push_back(float(last.tex[size_t(tc) * 2]));
+                o->uvs.push_back(float(last.tex[size_t(tc) * 2 + 1]));
+            }
+        } else {
+            id = it->second;
+        }
+        ids.push_back(id);
+    }
+    flush();
+    if (o->tris.empty()) {  // a point cloud
+        o->verts.resize(size_t(n_pts) * 3);
+        for (size_t i = 0; i < o->verts.size(); ++i) o->verts[i] = float(last.pts[i]);
+        o->uvs.clear();
+    }
     return 0;
 }
 
 }  // namespace
+
+// Any of the reference's surface formats by file extension (utils3d.py:389-423): .obj .ply .stl .vtk .wrl.
+// Same handle, accessors and error conventions as mvlm_obj_read; an unknown extension is MVLM_OBJ_ERR_ARGS
+// ("Can not read files with extenstion ...", utils3d.py:421-422).
+extern "C" int mvlm_mesh_read(const char* path, mvlm_obj** out, char* err, int err_len) {
+    if (!path || !out) { set_err(err, err_len, "mesh_read: bad arguments"); return MVLM_OBJ_ERR_ARGS; }
+    *out = nullptr;
+    const std::string ext = lower_ext(path);
+    if (ext == ".obj") return mvlm_obj_read(path, out, err, err_len);
+    if (ext != ".ply" && ext != ".stl" && ext != ".vtk" && ext != ".wrl") {
+        set_err(err, err_len, std::string("Can not read files with extension ") + ext);
+        return MVLM_OBJ_ERR_ARGS;
+    }
+    std::vector<char> data;
+    if (!read_file(path, &data)) { set_err(err, err_len, std::string("File ") + path + " does not exist."); return MVLM_OBJ_ERR_FILE; }
+    mvlm_obj* o = new mvlm_obj;
+    std::string msg;
+    int rc = ext == ".ply" ? read_ply(data, o, &msg) : ext == ".stl" ? read_stl(data, o, &msg) : ext == ".vtk" ? read_vtk(data, o, &msg)
+                                                                                                               : read_wrl(data, o, &msg);
+    const int64_t n_points = int64_t(o->verts.size() / 3);
+    if (!rc && n_points == 0) {
+        msg = "does not contain any points.";
+        rc = MVLM_OBJ_ERR_EMPTY;
+    }
+    if (!rc && !indices_ok(o->tris, n_points)) {
+        msg = "references a vertex that does not exist.";
+        rc = MVLM_OBJ_ERR_INDEX;
+    }
+    if (!rc && !o->uvs.empty() && o->uvs.size() != size_t(n_points) * 2) o->uvs.clear();  // partial texture coordinates: none
+    if (rc) {
+        delete o;
+        set_err(err, err_len, std::string("File ") + path + ": " + msg);
+        return rc;
+    }
+    o->n_positions = n_points;
+    *out = o;
+    return 0;
+}

@@ -16,13 +16,7 @@
 #include <vector>
 
 #include "../../include/mvlm_hip.h"
-
-struct mvlm_obj {
-    std::vector<float> verts;   // [V,3] corner-expanded (or the raw points for a point cloud)
-    std::vector<float> uvs;     // [V,2] or empty
-    std::vector<int32_t> tris;  // [T,3]
-    int64_t n_positions = 0;
-};
+#include "mesh_obj.h"
 
 namespace {
 

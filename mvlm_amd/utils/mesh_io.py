@@ -90,8 +90,9 @@ def _read_texture(jpg: Path):
         return None
 
 
-def _read_obj_native(path: Path):
-    """Parse with the library's reader (mvlm_obj_read, mvlm_amd/csrc/obj_reader.hip)."""
+def _read_obj_native(path: Path, any_format: bool = False):
+    """Parse with the library's readers: mvlm_obj_read (mvlm_amd/csrc/obj_reader.hip) or, with ``any_format``,
+    mvlm_mesh_read (mesh_readers.hip: .obj .ply .stl .vtk .wrl by extension)."""
     import ctypes as C
 
     from .. import _lib
@@ -99,9 +100,10 @@ def _read_obj_native(path: Path):
     lib = _lib.load()
     handle = C.c_void_p()
     err = C.create_string_buffer(512)
-    rc = lib.mvlm_obj_read(str(path).encode(), C.byref(handle), err, len(err))
+    read = lib.mvlm_mesh_read if any_format else lib.mvlm_obj_read
+    rc = read(str(path).encode(), C.byref(handle), err, len(err))
     if rc != 0:
-        raise ValueError(err.value.decode(errors="replace") or f"File {path}: OBJ reader failed ({rc})")
+        raise ValueError(err.value.decode(errors="replace") or f"File {path}: mesh reader failed ({rc})")
     try:
         nv, nt, has_uv = C.c_int64(), C.c_int64(), C.c_int()
         lib.mvlm_obj_info(handle, C.byref(nv), C.byref(nt), C.byref(has_uv))
@@ -162,6 +164,54 @@ def load_obj(path: Union[Path, str], load_texture: bool = True, reader: str = "n
         if tex_job is not None:
             tex_job.join()
     texture = box[0] if (tex_job is not None and uvs is not None) else None  # utils3d.py:26: only with tcoords
+    return Mesh(verts, tris, uvs, texture, path)
+
+
+SURFACE_SUFFIXES = (".obj", ".wrl", ".vtk", ".stl", ".ply")  # Utils3D.multi_read_surface, utils3d.py:389-423
+
+
+def find_texture(path: Union[Path, str], texture_file_name=None) -> Path | None:
+    """Texture file of a scan by the rules of ``Utils3D.multi_read_texture`` (utils3d.py:425-441): same stem
+    with ``.bmp``, then ``.png``, then ``.jpg`` - each one found replaces the earlier candidate, so .jpg wins
+    over .png over .bmp - and for BU-3DFE raw scans ``*RAW.wrl`` the ``*F3D.bmp`` next to it wins over all."""
+    if texture_file_name is not None:
+        return Path(texture_file_name)
+    path = Path(path)
+    found = None
+    for suffix in (".bmp", ".png", ".jpg"):
+        cand = path.with_suffix(suffix)
+        if cand.is_file():
+            found = cand
+    name = str(path)
+    if name.find("RAW.wrl") > 0:  # "BU-3DFE RAW file hack" (utils3d.py:438-441)
+        cand = Path(name.replace("RAW.wrl", "F3D.bmp"))
+        if cand.is_file():
+            found = cand
+    return found
+
+
+def load_mesh(path: Union[Path, str], load_texture: bool = True, texture_file_name=None) -> Mesh:
+    """Any surface format of the reference's legacy reader (``.obj .wrl .vtk .stl .ply``, utils3d.py:389-423)
+    with the texture looked up by ``find_texture`` (``.bmp / .png / .jpg``, :425-462) -> Mesh.  ``load_obj`` is
+    the live pipeline's stricter OBJ + same-stem JPEG ingest (utils3d.py:10-36)."""
+    path = Path(path)
+    if not path.is_file():
+        raise ValueError(f"File {path} does not exist.")
+    if path.suffix.lower() not in SURFACE_SUFFIXES:
+        raise ValueError(f"Can not read files with extension {path.suffix}")  # utils3d.py:421-422
+    tex_path = find_texture(path, texture_file_name) if load_texture else None
+    tex_job, box = None, [None]
+    if tex_path is not None and tex_path.suffix.lower() in (".bmp", ".png", ".jpg") and tex_path.is_file():
+        import threading
+
+        tex_job = threading.Thread(target=lambda: box.__setitem__(0, _read_texture(tex_path)), daemon=True)
+        tex_job.start()
+    try:
+        verts, tris, uvs = _read_obj_native(path, any_format=True)
+    finally:
+        if tex_job is not None:
+            tex_job.join()
+    texture = box[0] if uvs is not None else None
     return Mesh(verts, tris, uvs, texture, path)
 
 

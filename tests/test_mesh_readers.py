@@ -1,0 +1,285 @@
+"""The legacy multi-format surface / texture readers (reference Utils3D.multi_read_surface / multi_read_texture,
+src/mvlm/utils/utils3d.py:389-462) behind mvlm_mesh_read: .ply / .stl / .vtk / .wrl round trips against the arrays
+the files were written from, the texture lookup order, and an ASan + UBSan run on mutated files.  CPU only."""
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from mvlm_amd.utils import find_texture, load_mesh, load_obj
+from mvlm_amd.utils.mesh_io import write_obj
+from mvlm_amd.utils.synthetic import face_like_mesh
+
+
+def small_mesh():
+    m = face_like_mesh(9, 8, 3)
+    return m.verts, m.tris, m.uvs
+
+
+def write_ply(path, verts, tris, uvs=None, fmt="ascii"):
+    hdr = ["ply", f"format {fmt} 1.0", "comment made by the test", f"element vertex {len(verts)}",
+           "property float x", "property float y", "property float z"]
+    if uvs is not None:
+        hdr += ["property float s", "property float t"]
+    hdr += ["property uchar red", f"element face {len(tris)}", "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(hdr) + "\n").encode())
+        if fmt == "ascii":
+            for i, v in enumerate(verts):
+                vals = list(v) + (list(uvs[i]) if uvs is not None else [])
+                f.write((" ".join(repr(float(x)) for x in vals) + " 200\n").encode())
+            for t in tris:
+                f.write(f"3 {t[0]} {t[1]} {t[2]}\n".encode())
+        else:
+            e = "<" if fmt == "binary_little_endian" else ">"
+            for i, v in enumerate(verts):
+                f.write(struct.pack(e + "3f", *v))
+                if uvs is not None:
+                    f.write(struct.pack(e + "2f", *uvs[i]))
+                f.write(struct.pack("B", 200))
+            for t in tris:
+                f.write(struct.pack(e + "B3i", 3, *t))
+
+
+def write_stl(path, verts, tris, binary):
+    if binary:
+        with open(path, "wb") as f:
+            f.write(b"binary stl".ljust(80, b" "))
+            f.write(struct.pack("<I", len(tris)))
+            for t in tris:
+                f.write(struct.pack("<3f", 0, 0, 1))
+                for k in t:
+                    f.write(struct.pack("<3f", *verts[k]))
+                f.write(struct.pack("<H", 0))
+    else:
+        with open(path, "w") as f:
+            f.write("solid test\n")
+            for t in tris:
+                f.write(" facet normal 0 0 1\n  outer loop\n")
+                for k in t:
+                    f.write("   vertex " + " ".join(repr(float(x)) for x in verts[k]) + "\n")
+                f.write("  endloop\n endfacet\n")
+            f.write("endsolid test\n")
+
+
+def write_vtk(path, verts, tris, uvs, binary, v5=False):
+    with open(path, "wb") as f:
+        f.write(f"# vtk DataFile Version {'5.1' if v5 else '3.0'}\nvtk output\n{'BINARY' if binary else 'ASCII'}\nDATASET POLYDATA\n".encode())
+        f.write(f"POINTS {len(verts)} float\n".encode())
+        f.write(verts.astype(">f4").tobytes() if binary else ("\n".join(" ".join(repr(float(x)) for x in v) for v in verts) + "\n").encode())
+        if binary:
+            f.write(b"\n")
+        if v5:
+            off = np.arange(0, 3 * len(tris) + 1, 3)
+            f.write(f"POLYGONS {len(off)} {3 * len(tris)}\nOFFSETS vtktypeint64\n".encode())
+            f.write(off.astype(">i8").tobytes() + b"\n" if binary else (" ".join(str(x) for x in off) + "\n").encode())
+            f.write(b"CONNECTIVITY vtktypeint64\n")
+            f.write(tris.astype(">i8").tobytes() + b"\n" if binary else (" ".join(str(x) for x in tris.ravel()) + "\n").encode())
+        else:
+            f.write(f"POLYGONS {len(tris)} {4 * len(tris)}\n".encode())
+            cells = np.concatenate([np.full((len(tris), 1), 3), tris], axis=1)
+            f.write(cells.astype(">i4").tobytes() + b"\n" if binary else ("\n".join(" ".join(str(x) for x in c) for c in cells) + "\n").encode())
+        if uvs is not None:
+            f.write(f"POINT_DATA {len(verts)}\nTEXTURE_COORDINATES tcoords 2 float\n".encode())
+            f.write(uvs.astype(">f4").tobytes() + b"\n" if binary else ("\n".join(" ".join(repr(float(x)) for x in v) for v in uvs) + "\n").encode())
+
+
+def write_wrl(path, verts, tris, uvs, per_corner=False):
+    lines = ["#VRML V2.0 utf8", "# BU-3DFE style", "Shape {", " appearance Appearance { texture ImageTexture { url \"x_F3D.bmp\" } }",
+             " geometry IndexedFaceSet {", "  coord Coordinate { point ["]
+    lines += [f"   {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}," for v in verts]
+    lines += ["  ] }", "  coordIndex ["] + [f"   {t[0]}, {t[1]}, {t[2]}, -1," for t in tris] + ["  ]"]
+    if uvs is not None:
+        lines += ["  texCoord TextureCoordinate { point ["] + [f"   {float(u[0])!r} {float(u[1])!r}," for u in uvs] + ["  ] }"]
+        if per_corner:
+            lines += ["  texCoordIndex ["] + [f"   {t[0]}, {t[1]}, {t[2]}, -1," for t in tris] + ["  ]"]
+    lines += [" }", "}"]
+    path.write_text("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_round_trip(tmp_path, fmt):
+    verts, tris, uvs = small_mesh()
+    write_ply(tmp_path / "m.ply", verts, tris, uvs, fmt)
+    m = load_mesh(tmp_path / "m.ply")
+    np.testing.assert_array_equal(m.verts, verts)
+    np.testing.assert_array_equal(m.tris, tris)
+    np.testing.assert_array_equal(m.uvs, uvs)
+    write_ply(tmp_path / "n.ply", verts, tris, None, fmt)
+    assert load_mesh(tmp_path / "n.ply").uvs is None
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_stl_merges_coincident_points(tmp_path, binary):
+    verts, tris, _ = small_mesh()
+    write_stl(tmp_path / "m.stl", verts, tris, binary)
+    m = load_mesh(tmp_path / "m.stl")
+    # every triangle stores its own three corners; the reader merges them back (vtkSTLReader merging), numbering
+    # points in order of first appearance
+    order, seen = [], {}
+    for k in tris.ravel():
+        if k not in seen:
+            seen[k] = len(order)
+            order.append(k)
+    np.testing.assert_array_equal(m.verts, verts[order])
+    np.testing.assert_array_equal(m.tris, np.vectorize(seen.get)(tris))
+    assert m.uvs is None and m.texture is None
+
+
+@pytest.mark.parametrize("binary,v5", [(False, False), (True, False), (False, True), (True, True)])
+def test_vtk_polydata_round_trip(tmp_path, binary, v5):
+    verts, tris, uvs = small_mesh()
+    write_vtk(tmp_path / "m.vtk", verts, tris, uvs, binary, v5)
+    m = load_mesh(tmp_path / "m.vtk")
+    np.testing.assert_array_equal(m.verts, verts)
+    np.testing.assert_array_equal(m.tris, tris)
+    np.testing.assert_array_equal(m.uvs, uvs)
+
+
+@pytest.mark.parametrize("per_corner", [False, True])
+def test_vrml_indexed_face_set(tmp_path, per_corner):
+    verts, tris, uvs = small_mesh()
+    write_wrl(tmp_path / "m.wrl", verts, tris, uvs, per_corner)
+    m = load_mesh(tmp_path / "m.wrl")
+    order, seen = [], {}
+    for k in tris.ravel():           # corners are numbered in order of first use (like the OBJ reader)
+        if k not in seen:
+            seen[k] = len(order)
+            order.append(k)
+    np.testing.assert_array_equal(m.verts, verts[order])
+    np.testing.assert_array_equal(m.uvs, uvs[order])
+    np.testing.assert_array_equal(m.tris, np.vectorize(seen.get)(tris))
+
+
+def test_same_geometry_from_every_format(tmp_path):
+    """One mesh written in all five formats loads to the same surface: equal point sets and equal triangles (as
+    coordinate triples), whatever the point numbering of the format."""
+    verts, tris, uvs = small_mesh()
+    write_obj(tmp_path / "m.obj", verts, tris, uvs)
+    write_ply(tmp_path / "m.ply", verts, tris, uvs, "binary_little_endian")
+    write_stl(tmp_path / "m.stl", verts, tris, True)
+    write_vtk(tmp_path / "m.vtk", verts, tris, uvs, True)
+    write_wrl(tmp_path / "m.wrl", verts, tris, uvs)
+    ref = None
+    for ext in (".ply", ".stl", ".vtk", ".wrl", ".obj"):
+        m = load_mesh(tmp_path / f"m{ext}")
+        tri_xyz = np.sort(m.verts[m.tris].reshape(len(m.tris), 9).round(4), axis=0)
+        if ref is None:
+            ref = tri_xyz
+        np.testing.assert_allclose(tri_xyz, ref, atol=2e-4)   # the OBJ writer prints 6 decimals
+    a, b = load_mesh(tmp_path / "m.obj"), load_obj(tmp_path / "m.obj")
+    np.testing.assert_array_equal(a.verts, b.verts)
+    np.testing.assert_array_equal(a.tris, b.tris)
+
+
+def test_texture_lookup_order(tmp_path):
+    """multi_read_texture (utils3d.py:425-441): .bmp, then .png, then .jpg - the last one found wins; the BU-3DFE
+    *RAW.wrl -> *F3D.bmp rule wins over all; an explicit name is taken as is."""
+    from PIL import Image
+
+    verts, tris, uvs = small_mesh()
+    write_ply(tmp_path / "scan.ply", verts, tris, uvs)
+    assert find_texture(tmp_path / "scan.ply") is None and load_mesh(tmp_path / "scan.ply").texture is None
+
+    def img(name, colour):
+        Image.fromarray(np.full((4, 4, 3), colour, np.uint8)).save(tmp_path / name)
+
+    img("scan.bmp", (255, 0, 0))
+    assert find_texture(tmp_path / "scan.ply").name == "scan.bmp"
+    assert load_mesh(tmp_path / "scan.ply").texture[0, 0].tolist() == [255, 0, 0]
+    img("scan.png", (0, 255, 0))
+    assert find_texture(tmp_path / "scan.ply").name == "scan.png"
+    img("scan.jpg", (0, 0, 255))
+    assert find_texture(tmp_path / "scan.ply").name == "scan.jpg"
+    assert find_texture(tmp_path / "scan.ply", tmp_path / "scan.bmp").name == "scan.bmp"
+    assert load_mesh(tmp_path / "scan.ply", texture_file_name=tmp_path / "scan.png").texture[0, 0].tolist() == [0, 255, 0]
+    write_wrl(tmp_path / "F0001_NE00WH_RAW.wrl", verts, tris, uvs)
+    img("F0001_NE00WH_RAW.jpg", (9, 9, 9))
+    img("F0001_NE00WH_F3D.bmp", (7, 200, 7))
+    assert find_texture(tmp_path / "F0001_NE00WH_RAW.wrl").name == "F0001_NE00WH_F3D.bmp"
+    assert load_mesh(tmp_path / "F0001_NE00WH_RAW.wrl").texture[0, 0].tolist() == [7, 200, 7]
+    # a mesh without texture coordinates gets no texture (utils3d.py:26: only with tcoords)
+    write_stl(tmp_path / "scan.stl", verts, tris, True)
+    assert load_mesh(tmp_path / "scan.stl").texture is None
+
+
+def test_reader_errors(tmp_path):
+    with pytest.raises(ValueError, match="does not exist"):
+        load_mesh(tmp_path / "missing.ply")
+    (tmp_path / "x.off").write_text("OFF\n")
+    with pytest.raises(ValueError, match="Can not read files with extension"):
+        load_mesh(tmp_path / "x.off")
+    (tmp_path / "empty.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+    with pytest.raises(ValueError, match="does not contain any points"):
+        load_mesh(tmp_path / "empty.ply")
+    (tmp_path / "bad.ply").write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\n"
+                                      "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n3 0 1 2\n")
+    with pytest.raises(ValueError, match="does not exist"):
+        load_mesh(tmp_path / "bad.ply")
+    (tmp_path / "trunc.vtk").write_text("# vtk DataFile Version 3.0\nx\nASCII\nDATASET POLYDATA\nPOINTS 5 float\n0 0 0 1 1\n")
+    with pytest.raises(ValueError, match="POINTS"):
+        load_mesh(tmp_path / "trunc.vtk")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_mesh_readers_under_sanitizers(tmp_path):
+    exe = tmp_path / "harness"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-x", "c++", str(REPO / "mvlm_amd/csrc/mesh_readers.hip"), str(REPO / "mvlm_amd/csrc/obj_reader.hip"),
+                        str(REPO / "tests/native/mesh_reader_harness.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    verts, tris, uvs = small_mesh()
+    base = {}
+    write_ply(tmp_path / "a.ply", verts, tris, uvs, "ascii")
+    write_ply(tmp_path / "b.ply", verts, tris, uvs, "binary_little_endian")
+    write_ply(tmp_path / "c.ply", verts, tris, uvs, "binary_big_endian")
+    write_stl(tmp_path / "a.stl", verts, tris, False)
+    write_stl(tmp_path / "b.stl", verts, tris, True)
+    write_vtk(tmp_path / "a.vtk", verts, tris, uvs, False)
+    write_vtk(tmp_path / "b.vtk", verts, tris, uvs, True)
+    write_vtk(tmp_path / "c.vtk", verts, tris, uvs, True, v5=True)
+    write_wrl(tmp_path / "a.wrl", verts, tris, uvs, True)
+    names = ["a.ply", "b.ply", "c.ply", "a.stl", "b.stl", "a.vtk", "b.vtk", "c.vtk", "a.wrl"]
+    for n in names:
+        base[n] = (tmp_path / n).read_bytes()
+    rs = np.random.RandomState(5)
+    files = [tmp_path / n for n in names]
+    huge = [b"element vertex 2000000000\n", b"element face 99999999999\n", b"POINTS 700000000 float\n", b"POLYGONS 5 4000000000\n",
+            b"property list uchar int vertex_indices\n", b"coordIndex [ 0 1 99999999 -1 ]\n", b"point [ 1e400 nan inf ]\n"]
+    for i in range(270):
+        n = names[i % len(names)]
+        b = bytearray(base[n])
+        kind = (i // len(names)) % 5
+        if kind == 0:      # printable substitutions (hits the headers of the binary formats too)
+            for p in rs.randint(0, len(b), 12):
+                b[p] = rs.randint(32, 127)
+        elif kind == 1:    # truncation anywhere
+            b = b[: rs.randint(1, len(b))]
+        elif kind == 2:    # arbitrary binary noise
+            for p in rs.randint(0, len(b), 30):
+                b[p] = rs.randint(256)
+        elif kind == 3:    # counts the file cannot hold, spliced in after the first line
+            cut = b.find(b"\n") + 1
+            b = b[:cut] + huge[rs.randint(len(huge))] + b[cut:]
+        else:              # binary count fields overwritten with large values
+            for p in rs.randint(0, max(1, len(b) - 4), 4):
+                b[p:p + 4] = struct.pack("<I", int(rs.choice([0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 1 << 24])))
+        f = tmp_path / f"m{i}{n[1:]}"
+        f.write_bytes(bytes(b))
+        files.append(f)
+    for ext in (".ply", ".stl", ".vtk", ".wrl"):
+        (tmp_path / f"empty{ext}").write_bytes(b"")
+        files.append(tmp_path / f"empty{ext}")
+    files.append(tmp_path / "does_not_exist.ply")
+    r = subprocess.run([str(exe)] + [str(f) for f in files], capture_output=True, text=True,
+                       env={"ASAN_OPTIONS": "detect_leaks=1:allocator_may_return_null=1", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(files)
+    for k in range(len(names)):
+        assert " ok " in lines[k] and lines[k].endswith("bad_indices=0"), lines[k]
+    assert all(("rc=" in ln) or ln.endswith("bad_indices=0") for ln in lines)   # parsed output is always in range
