@@ -187,9 +187,11 @@ def main():
                     help="N > 1: strong = the config's view count sharded over the ranks (BASELINE), weak = that many per rank")
     ap.add_argument("--views-total", type=int, default=0, help="override the config's view count")
     ap.add_argument("--device-batch", type=int, default=128)
-    ap.add_argument("--no-kernel-profile", action="store_true",
-                    help="time the steps as the product runs them (replayed launch graphs); per-kernel HIP events then come "
-                         "from a separate pass after the timed region (always so for N > 1)")
+    ap.add_argument("--profile-in-timed", action="store_true",
+                    help="record the per-kernel HIP events inside the timed steps (forces the launch-by-launch path, ~2 %% "
+                         "slower than the replayed launch graph the product runs); default: time the product path and "
+                         "record the events over the same number of steps right after the timed region")
+    ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
     ap.add_argument("--cpu-views", type=int, default=-1, help="views in the CPU-baseline sample (-1 = the whole workload, at most 96; 0 = skip)")
     args = ap.parse_args()
 
@@ -258,11 +260,11 @@ def main():
     r_ctx = pipe.renderer_3d.ctx
     for _ in range(args.warmup):
         step()
-    # Per-kernel HIP events on the launch stream.  N = 1: live over the timed region (the events force the
-    # launch-by-launch path; at the 96-view workload it runs within noise of the replayed graph).  N > 1 or
-    # --no-kernel-profile: the timed steps run exactly as the product does (graph replay) and the same number
-    # of steps is profiled right after the timed region.
-    profile_in_timed = world == 1 and not args.no_kernel_profile
+    # Per-kernel HIP events on the launch stream need the launch-by-launch path (two event records around
+    # every launch; ~2 % slower than the captured launch graph the product replays).  Default: the timed steps
+    # run exactly as the product does and the same number of steps is profiled right after the timed region;
+    # --profile-in-timed (N = 1 only) records the events inside the timed steps instead.
+    profile_in_timed = world == 1 and args.profile_in_timed
     prof, per_slot = {}, {}
     render_ms, render_calls = [0.0], [0]
     cap = 1024

@@ -196,6 +196,32 @@ class Pipeline(abc.ABC):
 
         rot = view_rotations(transform_stack)  # once per call: renderer and estimator share it
         tm = self._timer
+        if sharded:
+            # One RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) and broadcasts the
+            # [NL, 8] index table.  The table for the survivor counts the quantile filter is expected to yield is
+            # drawn and broadcast NOW, before this step's GPU work is enqueued (a collective behind the network
+            # would stall every rank's host until the network has finished); should the real counts differ (tied /
+            # NaN scores, absolute mode) rank 0 rewinds its RNG and the table is drawn and broadcast again.
+            nl_all = p2.get_lm_count()
+            spec = e3.expected_counts(nl_all, n_total)
+            dev_t = torch.device("cuda", self.device)
+            pre = {"state": np.random.get_state() if rank == 0 else None, "draws": None}
+            if spec is not None:
+                quiet, e3.verbose = e3.verbose, False
+                try:
+                    first = e3.draw_ransac_indices(spec) if rank == 0 else None
+                finally:
+                    e3.verbose = quiet
+                pre["draws"] = parallel.broadcast_int32(first, (nl_all, 8), dev_t)
+
+            def sharded_draws(counts):
+                if pre["draws"] is not None and np.array_equal(counts, spec):
+                    return pre["draws"]
+                if rank == 0:
+                    np.random.set_state(pre["state"])
+                draws = e3.draw_ransac_indices(counts) if rank == 0 else None
+                return parallel.broadcast_int32(draws, (len(counts), 8), dev_t)
+
         with tm.stage("render"):
             # one image stack / maxima buffer per view count, reused from call to call: stable addresses let the
             # predictor replay its captured launch graph instead of re-enqueueing ~160 kernels per mesh
@@ -228,19 +254,18 @@ class Pipeline(abc.ABC):
         with tm.stage("consensus"):
             draws_fn = None
             if sharded:
-                # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) from the survivor
-                # counts every rank computed, and broadcasts the [NL, 8] index table
-                def draws_fn(counts):
-                    draws = e3.draw_ransac_indices(counts) if rank == 0 else None
-                    return parallel.broadcast_int32(draws, (len(counts), 8), maxima.device)
-
+                draws_fn = sharded_draws
             if self.visualize_rays:
                 self._rays = (mesh, starts.cpu().numpy(), ends.cpu().numpy())
-            out, err, _ = e3.consensus_device(maxima, starts, ends, draws_fn=draws_fn)
-            error = e3.mean_error(err.cpu().numpy())
+            out, err, verify = e3.consensus_device(maxima, starts, ends, draws_fn=draws_fn, deferred=True)
 
         with tm.stage("project"):
-            landmarks = e3.project_device(mesh, out).cpu().numpy()
+            # the snap is enqueued before anything is fetched: one wait per mesh, at the end
+            snapped = e3.project_device(mesh, out)
+            if verify():  # the RANSAC draws had to be repeated for other survivor counts (tied / NaN scores)
+                snapped = e3.project_device(mesh, out)
+            landmarks = snapped.cpu().numpy()
+            error = e3.mean_error(err.cpu().numpy())
             r3.check()  # deferred renderer status (the .cpu() above already synchronised)
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error

@@ -67,10 +67,24 @@ class HipEstimator3D:
             draws[lm] = np.random.randint(0, k, size=8)
         return draws
 
-    def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None):
+    def expected_counts(self, n_landmarks: int, n_views: int):
+        """Survivor count per landmark that the quantile filter yields for distinct, finite scores:
+        ``value > np.quantile(values, q)`` (estimator3d.py:140-147) keeps N - 1 - floor(q (N - 1)) of N values.
+        None when the counts cannot be known before the scores exist (absolute mode, unknown mode)."""
+        if self.mode != "quantile" or not (0.0 <= float(self.threshold_quantile) <= 1.0) or n_views < 1:
+            return None
+        k = n_views - 1 - int(np.floor(float(self.threshold_quantile) * (n_views - 1)))
+        return np.full(n_landmarks, k, dtype=np.int32)
+
+    def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None, deferred: bool = False):
         """Filter + one-shot RANSAC + LSQ on device.  ``draws_fn(counts) -> int32[NL,8]`` replaces the local
         RNG draw (the sharded pipeline broadcasts rank 0's).  Returns (landmarks f64[NL,3] tensor,
-        per-landmark error f64[NL] tensor, counts int32[NL] numpy)."""
+        per-landmark error f64[NL] tensor, counts int32[NL] numpy).
+
+        ``deferred=True`` returns ``(landmarks, error, verify)`` instead and does not wait for the GPU:
+        ``verify()`` - to be called once, after the caller has enqueued whatever consumes the landmarks - fetches
+        the survivor counts, and if the draws were made for other counts (see below) repeats them and the solve
+        IN PLACE and returns True: the caller must then redo the work it had enqueued on the landmarks."""
         torch, dev = self._torch()
         if self.mode not in _MODES:
             raise ValueError(f"Unknown mode for line matching in Estimator: {self.mode}")
@@ -81,17 +95,56 @@ class HipEstimator3D:
             self.ctx.handle, C.c_void_p(landmarks_dev.data_ptr()), n, nl, _MODES[self.mode],
             float(self.threshold_quantile), float(self.threshold_absolute), C.c_void_p(mask.data_ptr()),
             C.c_void_p(count.data_ptr())), ValueError)
-        counts = count.cpu().numpy()
-        draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(counts), dtype=np.int32)
-        if draws.shape != (nl, 8):
-            raise ValueError(f"RANSAC draws must be [{nl}, 8], got {draws.shape}")
-        draws_dev = torch.from_numpy(draws).to(dev)
         out = torch.empty((nl, 3), dtype=torch.float64, device=dev)
         err = torch.empty((nl,), dtype=torch.float64, device=dev)
-        self.ctx.check(self.ctx.lib.mvlm_consensus_solve(
-            self.ctx.handle, C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()), C.c_void_p(mask.data_ptr()),
-            C.c_void_p(count.data_ptr()), C.c_void_p(draws_dev.data_ptr()), n, nl, C.c_void_p(out.data_ptr()),
-            C.c_void_p(err.data_ptr())))
+
+        def solve(counts_for_draws):
+            draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(counts_for_draws), dtype=np.int32)
+            if draws.shape != (nl, 8):
+                raise ValueError(f"RANSAC draws must be [{nl}, 8], got {draws.shape}")
+            draws_dev = torch.from_numpy(draws).to(dev, non_blocking=True)
+            self.ctx.check(self.ctx.lib.mvlm_consensus_solve(
+                self.ctx.handle, C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()), C.c_void_p(mask.data_ptr()),
+                C.c_void_p(count.data_ptr()), C.c_void_p(draws_dev.data_ptr()), n, nl, C.c_void_p(out.data_ptr()),
+                C.c_void_p(err.data_ptr())))
+
+        # The draws need each landmark's survivor count k (the reference draws from range(k), estimator3d.py:105),
+        # which only exists once the network has finished: waiting for it stalls the host in the middle of the
+        # step.  In quantile mode k is known beforehand unless scores tie or are NaN: "value > np.quantile(values,
+        # q)" keeps N - 1 - floor(q (N - 1)) of N distinct values.  So the draws are made for that k while the GPU
+        # is still busy, the solve is enqueued behind the filter, and the real counts are compared afterwards; a
+        # mismatch rewinds the global RNG and repeats draws + solve with the real counts, so the stream of random
+        # numbers consumed - and every result - is the one the synchronous order gives.
+        expected = self.expected_counts(nl, n)
+        state = {"counts": None}
+        if expected is not None:
+            rng_state = np.random.get_state()
+            verbose, self.verbose = self.verbose, False  # "Not enough points" is reported by the pass that counts
+            try:
+                solve(expected)
+            finally:
+                self.verbose = verbose
+
+            def verify() -> bool:
+                counts = state["counts"] = count.cpu().numpy()
+                if not np.array_equal(counts, expected):
+                    np.random.set_state(rng_state)
+                    solve(counts)
+                    return True
+                if self.verbose and expected[0] < 3:
+                    for lm in range(nl):
+                        print("Not enough points for good estimate of landmark lm_no", lm, int(expected[0]))
+                return False
+        else:
+            state["counts"] = count.cpu().numpy()
+            solve(state["counts"])
+
+            def verify() -> bool:
+                return False
+        if deferred:
+            return out, err, verify
+        verify()
+        counts = state["counts"]
         return out, err, counts
 
     def project_device(self, mesh: Mesh, landmarks_dev):

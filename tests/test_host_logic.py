@@ -231,8 +231,75 @@ def test_create_pipeline_names():
 
     with pytest.raises(ValueError, match="Unknown pipeline"):
         pipeline.create_pipeline("nope")
-    with pytest.raises(ValueError, match="third-party"):
-        pipeline.create_pipeline("MediaPipe")
+    assert {"MediaPipePipeline", "DlibPipeline", "FaceAlignmentPipeline"} <= set(pipeline.__all__)
+
+
+def test_third_party_detector_adapters(tmp_path, monkeypatch):
+    """The wrappers around the reference's third-party detectors: loud ImportError without the library, and with a
+    stand-in library the output conventions of mediapipepredictor.py:35-48 / face_alignmentpredictor.py:37-52."""
+    import sys
+    import types
+
+    from mvlm_amd.prediction import DlibPredictor, FaceAlignmentPredictor, MediaPipePredictor
+
+    for cls in (MediaPipePredictor, DlibPredictor, FaceAlignmentPredictor):
+        with pytest.raises(ImportError, match="not installed"):
+            cls()
+    rs = np.random.RandomState(0)
+    stack = rs.rand(3, 256, 256, 4).astype(np.float32)
+
+    # face_alignment stand-in: view 1 has no face
+    xy = rs.uniform(-5, 260, (68, 2)).astype(np.float32)   # some points outside the image: the depth lookup clamps
+    fa = types.ModuleType("face_alignment")
+    fa.LandmarksType = types.SimpleNamespace(TWO_D=1)
+
+    class FaceAlignment:
+        def __init__(self, *a, **k):
+            self.calls = 0
+
+        def get_landmarks_from_image(self, img, **k):
+            assert img.dtype == np.uint8 and img.shape == (256, 256, 3)
+            self.calls += 1
+            return None if self.calls == 2 else [xy]
+
+    fa.FaceAlignment = FaceAlignment
+    monkeypatch.setitem(sys.modules, "face_alignment", fa)
+    lms, valid = FaceAlignmentPredictor(device="cpu").predict_landmarks_from_images(stack)
+    assert lms.shape == (68, 3, 3) and valid.tolist() == [True, False, True]
+    assert np.isnan(lms[:, 1]).all()
+    np.testing.assert_array_equal(lms[:, 0, 0], xy[:, 1])
+    np.testing.assert_array_equal(lms[:, 0, 1], xy[:, 0])
+    r, c = np.clip(xy[:, 1], 0, 255).astype(int), np.clip(xy[:, 0], 0, 255).astype(int)
+    np.testing.assert_array_equal(lms[:, 2, 2], stack[2, r, c, 3])
+
+    # mediapipe stand-in
+    mp = types.ModuleType("mediapipe")
+    mp.ImageFormat = types.SimpleNamespace(SRGB=1)
+    mp.Image = lambda image_format, data: data
+    pt = [types.SimpleNamespace(x=rs.rand(), y=rs.rand(), z=rs.rand() - 0.5) for _ in range(478)]
+    python = types.ModuleType("mediapipe.tasks.python")
+    python.BaseOptions = lambda model_asset_path: model_asset_path
+    vision = types.ModuleType("mediapipe.tasks.python.vision")
+    vision.RunningMode = types.SimpleNamespace(IMAGE=0)
+    vision.FaceLandmarkerOptions = lambda **k: k
+
+    class FaceLandmarker:
+        @staticmethod
+        def create_from_options(options):
+            return types.SimpleNamespace(detect=lambda img: types.SimpleNamespace(face_landmarks=[pt] if img[0, 0, 0] < 250 else []))
+
+    vision.FaceLandmarker = FaceLandmarker
+    for name, mod in (("mediapipe", mp), ("mediapipe.tasks", types.ModuleType("mediapipe.tasks")),
+                      ("mediapipe.tasks.python", python), ("mediapipe.tasks.python.vision", vision)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    (tmp_path / "m.task").write_bytes(b"x")
+    stack[2, 0, 0, 0] = 1.0   # this view: "no face"
+    lms, valid = MediaPipePredictor(model_asset_path=tmp_path / "m.task").predict_landmarks_from_images(stack)
+    assert lms.shape == (478, 3, 3) and valid.tolist() == [True, True, False]
+    want = np.array([[p.y * 256, p.x * 256, -p.z * 256] for p in pt], np.float32)
+    np.testing.assert_array_equal(lms[:, 0], want)
+    with pytest.raises(FileNotFoundError):
+        MediaPipePredictor(model_asset_path=tmp_path / "missing.task")
 
 
 def test_rng_draw_shortcut_is_the_same_stream():
