@@ -1,13 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace stats + PMC passes of bench.py.
-# usage: tools/profile_gpu.sh <tag> [bench args...]
+# usage: WORKLOAD="bu3dfe-rgbd-96:96v/gpu" tools/profile_gpu.sh <tag> [bench args...]
+# (WORKLOAD = bench.py's workload key "<config>:<views per GPU>v/gpu" of the profiled command; it is stored in
+#  traffic.json so that bench.py only quotes HBM traffic measured on the workload it is running)
 set -u
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp MVLM_BENCH_NO_INGEST=1
-ARGS="--steps 2 --warmup 1 --cpu-views 0 $*"
+ARGS="--steps 3 --warmup 2 --cpu-views 0 $*"
 echo "== kernel trace" | tee -a $OUT/log.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "rc=$?" >> $OUT/log.txt
@@ -23,7 +25,7 @@ if [ "${PMC:-1}" = "1" ]; then
   echo "== pmc write" | tee -a $OUT/log.txt
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
   echo "rc=$?" >> $OUT/log.txt
-  python3 $ROOT/tools/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1
+  python3 $ROOT/tools/summarize_pmc.py $OUT "${WORKLOAD:-bu3dfe-rgbd-96:96v/gpu}" > $OUT/pmc_summary.txt 2>&1
   cat $OUT/pmc_summary.txt
 fi
 # keep the merged-back payload small

@@ -6,6 +6,7 @@ from collections import defaultdict
 from pathlib import Path
 
 out = Path(sys.argv[1])
+WORKLOAD = sys.argv[2] if len(sys.argv) > 2 else "unknown"  # bench.py's workload key, e.g. "bu3dfe-rgbd-96:96v/gpu"
 agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(int)
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
@@ -68,4 +69,17 @@ for k, a in agg.items():
     write = a["WRITE_SIZE"] * 1024 / nw
     traffic[VARIANT[m.group(1)]] = {"launches": nf, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                                     "hbm_bytes_per_launch": fetch + write}
-(out / "traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True))
+# the rasteriser: the five kernels of one mvlm_render together, per render call
+RASTER = ("transform_kernel", "classify_kernel", "scan_kernel", "bin_fill_kernel", "tile_kernel")
+rf = rw = 0.0
+calls = 0
+for k, a in agg.items():
+    if any(k.startswith(r) or ("::" + r) in k or k.split("(")[0].endswith(r) for r in RASTER):
+        rf += 2 * a.get("FETCH_SIZE", 0) * 1024
+        rw += a.get("WRITE_SIZE", 0) * 1024
+        if "tile_kernel" in k:
+            calls = cnt.get((k, "WRITE_SIZE"), 0)
+if calls:
+    traffic["rasteriser"] = {"launches": calls, "fetch_bytes_per_launch": rf / calls, "write_bytes_per_launch": rw / calls,
+                             "hbm_bytes_per_launch": (rf + rw) / calls}
+(out / "traffic.json").write_text(json.dumps({"workload": WORKLOAD, "kernels": traffic}, indent=1, sort_keys=True))
