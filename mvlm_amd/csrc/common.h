@@ -35,6 +35,29 @@
     } while (0)
 
 // ---------------------------------------------------------------------------------------
+// np.argmax order on floats (paulsenpredictor.py:123): NaN counts as the maximum, the first one wins; otherwise the
+// larger value, the lower index on ties (+0 == -0).  argmax_key maps a float to an int whose integer order is that
+// order; argmax_value maps the winning key back (a NaN comes back as a quiet NaN).
+__host__ __device__ inline int argmax_key(float v) {
+    v = v + 0.0f;  // -0 -> +0
+    int b;
+    __builtin_memcpy(&b, &v, 4);
+    if (v != v) return 0x7fffffff;
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__host__ __device__ inline float argmax_value(int key) {
+    int b = key == 0x7fffffff ? 0x7fc00000 : (key >= 0 ? key : (key ^ 0x7fffffff));
+    float v;
+    __builtin_memcpy(&v, &b, 4);
+    return v;
+}
+// does (ov, oi) precede (bv, bi) in that order?
+__host__ __device__ inline bool argmax_better(float ov, int oi, float bv, int bi) {
+    const int ok = argmax_key(ov), bk = argmax_key(bv);
+    return ok > bk || (ok == bk && oi < bi);
+}
+
+// ---------------------------------------------------------------------------------------
 // One convolution launch.  All tensors are planar NCHW f32; a tensor argument is a base
 // pointer + total channel count + first channel, so a launch can read or write a channel
 // slice of a wider tensor (the residual block's concat, paulsenpredictor.py:273).

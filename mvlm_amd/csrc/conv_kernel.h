@@ -742,18 +742,15 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 const float bias = a.bias ? a.bias[coc] : 0.f;
                 // value first: max over this lane's pixels, then over the 32 lanes of the half-wave with
                 // DPP-modified v_max (row_shr 1, 2, 4, 8 leave each 16-lane row's maximum in its lane 15,
-                // row_bcast15 hands it to the next row: lanes 31 / 63 hold the half-waves' maxima)
-                float vals[C::NT];
-                float best_v = -INFINITY;
+                // row_bcast15 hands it to the next row: lanes 31 / 63 hold the half-waves' maxima).  The values
+                // are compared as argmax_key integers, i.e. in np.argmax's order (NaN = maximum, +0 == -0)
+                int keys[C::NT];
+                int best_k = int(0x807fffff);  // argmax_key(-inf)
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n) {
-                    vals[n] = lane_ok[n] ? acc[m][n][r] + bias : -INFINITY;
-                    best_v = fmaxf(best_v, vals[n]);
+                    keys[n] = lane_ok[n] ? argmax_key(acc[m][n][r] + bias) : int(0x807fffff);
+                    best_k = max(best_k, keys[n]);
                 }
-                auto dpp_f = [](float x, auto ctrl_c, auto rows_c) {
-                    const int xi = __float_as_int(x);
-                    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false));
-                };
                 auto dpp_i = [](int x, auto ctrl_c, auto rows_c) {
                     return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false);
                 };
@@ -764,18 +761,19 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 using BC15 = std::integral_constant<int, 0x142>;
                 using ALL = std::integral_constant<int, 0xf>;
                 using ODD = std::integral_constant<int, 0xa>;
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR1{}, ALL{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR2{}, ALL{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR4{}, ALL{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR8{}, ALL{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, BC15{}, ODD{}));
-                const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 31));
-                const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 63));
-                best_v = half ? m_hi : m_lo;
+                best_k = max(best_k, dpp_i(best_k, SHR1{}, ALL{}));
+                best_k = max(best_k, dpp_i(best_k, SHR2{}, ALL{}));
+                best_k = max(best_k, dpp_i(best_k, SHR4{}, ALL{}));
+                best_k = max(best_k, dpp_i(best_k, SHR8{}, ALL{}));
+                best_k = max(best_k, dpp_i(best_k, BC15{}, ODD{}));
+                const int m_lo = __builtin_amdgcn_readlane(best_k, 31);
+                const int m_hi = __builtin_amdgcn_readlane(best_k, 63);
+                best_k = half ? m_hi : m_lo;
+                const float best_v = argmax_value(best_k);
                 // then the first pixel (row-major) that attains it
                 int best_i = 0x7fffffff;
 #pragma unroll
-                for (int n = 0; n < C::NT; ++n) best_i = min(best_i, vals[n] == best_v ? ppix[n] : 0x7fffffff);
+                for (int n = 0; n < C::NT; ++n) best_i = min(best_i, keys[n] == best_k ? ppix[n] : 0x7fffffff);
                 best_i = min(best_i, dpp_i(best_i, SHR1{}, ALL{}));
                 best_i = min(best_i, dpp_i(best_i, SHR2{}, ALL{}));
                 best_i = min(best_i, dpp_i(best_i, SHR4{}, ALL{}));
@@ -794,27 +792,27 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             using SHR2 = std::integral_constant<int, 0x112>;
             using SHR4 = std::integral_constant<int, 0x114>;
             using SHR8 = std::integral_constant<int, 0x118>;
-            auto dpp_f = [](float x, auto ctrl_c) {
-                const int xi = __float_as_int(x);
-                return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl_c)::value, 0xf, 0xf, false));
-            };
             auto dpp_i = [](int x, auto ctrl_c) { return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, 0xf, 0xf, false); };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float best_v = -INFINITY;
+                int keys[C::NT16];
+                int best_k = int(0x807fffff);  // argmax_key(-inf)
 #pragma unroll
-                for (int j = 0; j < C::NT16; ++j) best_v = fmaxf(best_v, val16[j][i]);
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR1{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR2{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR4{}));
-                best_v = fmaxf(best_v, dpp_f(best_v, SHR8{}));  // lane 15 of every row: the row's maximum
-                const int bi = __float_as_int(best_v);
-                const int r0 = __builtin_amdgcn_readlane(bi, 15), r1 = __builtin_amdgcn_readlane(bi, 31);
-                const int r2 = __builtin_amdgcn_readlane(bi, 47), r3 = __builtin_amdgcn_readlane(bi, 63);
-                best_v = __int_as_float(q16 == 0 ? r0 : q16 == 1 ? r1 : q16 == 2 ? r2 : r3);
+                for (int j = 0; j < C::NT16; ++j) {
+                    keys[j] = argmax_key(val16[j][i]);
+                    best_k = max(best_k, keys[j]);
+                }
+                best_k = max(best_k, dpp_i(best_k, SHR1{}));
+                best_k = max(best_k, dpp_i(best_k, SHR2{}));
+                best_k = max(best_k, dpp_i(best_k, SHR4{}));
+                best_k = max(best_k, dpp_i(best_k, SHR8{}));  // lane 15 of every row: the row's maximum
+                const int r0 = __builtin_amdgcn_readlane(best_k, 15), r1 = __builtin_amdgcn_readlane(best_k, 31);
+                const int r2 = __builtin_amdgcn_readlane(best_k, 47), r3 = __builtin_amdgcn_readlane(best_k, 63);
+                best_k = q16 == 0 ? r0 : q16 == 1 ? r1 : q16 == 2 ? r2 : r3;
+                const float best_v = argmax_value(best_k);
                 int best_i = 0x7fffffff;
 #pragma unroll
-                for (int j = 0; j < C::NT16; ++j) best_i = min(best_i, val16[j][i] == best_v ? pix16[j] : 0x7fffffff);
+                for (int j = 0; j < C::NT16; ++j) best_i = min(best_i, keys[j] == best_k ? pix16[j] : 0x7fffffff);
                 best_i = min(best_i, dpp_i(best_i, SHR1{}));
                 best_i = min(best_i, dpp_i(best_i, SHR2{}));
                 best_i = min(best_i, dpp_i(best_i, SHR4{}));

@@ -57,7 +57,7 @@ __global__ void amax_final_kernel(const float* __restrict__ val, const int* __re
     for (int i = threadIdx.x; i < parts; i += blockDim.x) {
         const float ov = v[i];
         const int oi = ix[i];
-        if (ov > bv || (ov == bv && oi < bi)) {
+        if (argmax_better(ov, oi, bv, bi)) {
             bv = ov;
             bi = oi;
         }
@@ -65,7 +65,7 @@ __global__ void amax_final_kernel(const float* __restrict__ val, const int* __re
     for (int s = 32; s >= 1; s >>= 1) {
         const float ov = __shfl_xor(bv, s);
         const int oi = __shfl_xor(bi, s);
-        if (ov > bv || (ov == bv && oi < bi)) {
+        if (argmax_better(ov, oi, bv, bi)) {
             bv = ov;
             bi = oi;
         }
@@ -79,7 +79,7 @@ __global__ void amax_final_kernel(const float* __restrict__ val, const int* __re
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < int(blockDim.x >> 6); ++w)
-            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) {
+            if (argmax_better(sv[w], si[w], bv, bi)) {
                 bv = sv[w];
                 bi = si[w];
             }
@@ -100,7 +100,7 @@ __global__ void heatmap_maxima_kernel(const float* __restrict__ heat, int n_view
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < size * size; i += blockDim.x) {
         const float ov = hm[i];
-        if (ov > bv || (ov == bv && i < bi)) {
+        if (argmax_better(ov, i, bv, bi)) {
             bv = ov;
             bi = i;
         }
@@ -108,7 +108,7 @@ __global__ void heatmap_maxima_kernel(const float* __restrict__ heat, int n_view
     for (int s = 32; s >= 1; s >>= 1) {
         const float ov = __shfl_xor(bv, s);
         const int oi = __shfl_xor(bi, s);
-        if (ov > bv || (ov == bv && oi < bi)) {
+        if (argmax_better(ov, oi, bv, bi)) {
             bv = ov;
             bi = oi;
         }
@@ -122,7 +122,7 @@ __global__ void heatmap_maxima_kernel(const float* __restrict__ heat, int n_view
     }
     __syncthreads();
     for (int w = 0; w < int(blockDim.x >> 6); ++w)
-        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) {
+        if (argmax_better(sv[w], si[w], bv, bi)) {
             bv = sv[w];
             bi = si[w];
         }

@@ -321,3 +321,49 @@ def test_pipeline_steps_replay_the_graph_and_match_eager(tmp_path):
         assert gerr == werr
     st = pipe.predictor_2d.execution_stats()
     assert st["graph_replays"] >= 3 and st["graph_failures"] == 0
+
+
+# ---- np.argmax order incl. NaN and signed zeros (paulsenpredictor.py:123) -------------------------------------
+def test_heatmap_maxima_nan_and_signed_zero_like_numpy():
+    from mvlm_amd import _lib
+    from oracle import cnn as ocnn
+
+    ctx = _lib.get_context(0)
+    rs = np.random.RandomState(3)
+    hm = rs.standard_normal((1, 6, 64, 64)).astype(np.float32)
+    hm[0, 0, 5, 7] = np.nan            # np.argmax: the first NaN is the maximum
+    hm[0, 0, 40, 3] = np.nan
+    hm[0, 1, 9, 9] = np.inf            # a NaN later in the plane still wins over +inf
+    hm[0, 1, 50, 50] = np.nan
+    hm[0, 2] = 0.0
+    hm[0, 2, 0, 0] = -0.0              # -0 == +0: the first element wins, not the first +0
+    hm[0, 3] = -np.inf                 # constant -inf plane: index 0
+    hm[0, 4, 63, 63] = 1e30            # ordinary maximum in the last pixel
+    for method in (0, 1):
+        out = torch.empty((6, 1, 3), dtype=torch.float32, device="cuda")
+        hd = dev(hm)
+        ctx.check(ctx.lib.mvlm_heatmap_maxima(ctx.handle, C.c_void_p(hd.data_ptr()), 1, 6, 64, method, C.c_void_p(out.data_ptr())))
+        want = ocnn.maxima_from_heatmaps(hm, "simple" if method == 0 else "moment")
+        np.testing.assert_array_equal(out.cpu().numpy(), want)      # assert_array_equal treats NaN == NaN
+    assert np.isnan(want[0, 0, 2]) and want[0, 0, 0] == 4 and want[0, 0, 1] == 6.5 and want[1, 0, 0] == 49
+
+
+def test_fused_argmax_nan_plane_like_numpy():
+    """A NaN bias in conv11 makes one landmark's whole heatmap NaN: np.argmax returns pixel 0 and the value NaN
+    (paulsenpredictor.py:123-127); the fused conv11 + argmax kernels must do the same and leave the others alone."""
+    from conftest import seeded_images
+    from mvlm_amd import weights
+    from mvlm_amd.prediction import DTU3DPredictor
+
+    sd = weights.synthetic_state_dict(73, 3, seed=8)
+    imgs = dev(seeded_images(31, 3))
+    clean = DTU3DPredictor(image_mode="RGB", weights=sd, verbose=False).predict_device(imgs).cpu().numpy()
+    sd = dict(sd)
+    sd["conv11.bias"] = sd["conv11.bias"].copy()
+    sd["conv11.bias"][[3, 70]] = np.nan          # one channel of the 32-row tiles, one of the 16-row strip
+    got = DTU3DPredictor(image_mode="RGB", weights=sd, verbose=False).predict_device(imgs).cpu().numpy()
+    for lm in (3, 70):
+        np.testing.assert_array_equal(got[lm, :, :2], np.tile(np.float32([-1.0, -0.5]), (3, 1)))
+        assert np.isnan(got[lm, :, 2]).all()
+    keep = [i for i in range(73) if i not in (3, 70)]
+    np.testing.assert_array_equal(got[keep], clean[keep])
