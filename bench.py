@@ -212,10 +212,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the communication libraries may log to fd 1 while they connect (gloo does): stdout is reserved for
+        # the ONE JSON line, so fd 1 points at stderr until the process group exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if share_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         backend = f"{dist.get_backend()} world_size {dist.get_world_size()}"
 
     from mvlm_amd import arch, config, parallel, weights

@@ -135,7 +135,10 @@ __device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, f
 // spread over the k-steps so its address arithmetic, loads, BatchNorm and LDS writes run in the
 // shadow of the 64-cycle MFMAs: loads are issued during the first half of the steps, written to
 // the other stage `st_next` half a chunk (~9k cycles) later.
-template <class C, bool STAGE_NEXT>
+// TR: the accumulators hold the TRANSPOSED tile (rows = pixels, columns = output channels): the operands of
+// every MFMA are swapped, nothing else changes.  The fused-argmax launches use it: a lane then owns ONE output
+// channel and 16 pixels per tile, so the per-channel maximum is a chain of in-register compares.
+template <class C, bool STAGE_NEXT, bool TR = false>
 __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st, float* st_next, int cb_next, int tid,
                                               unsigned HWin, const float* sbn, int woff, const int (&pixoff)[C::NT],
                                               const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
@@ -177,7 +180,8 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             constexpr int i = decltype(ic)::value;
             constexpr int m = i / C::NT, n = i % C::NT;
             if constexpr (i < LEAD)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+                acc[m][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ks & 1][n], av[ks & 1][m], acc[m][n], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STAGE_NEXT) {
@@ -198,11 +202,14 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             constexpr int i = decltype(ic)::value;
             constexpr int m = i / C::NT, n = i % C::NT;
             if constexpr (i >= LEAD)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
+                acc[m][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ks & 1][n], av[ks & 1][m], acc[m][n], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][n], acc[m][n], 0, 0, 0);
         });
         if constexpr (C::TAIL16 && (ks & 1) == 1) {
 #pragma unroll
-            for (int j = 0; j < C::NT16; ++j) acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16[j], acc16[j], 0, 0, 0);
+            for (int j = 0; j < C::NT16; ++j)
+                acc16[j] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(b16[j], a16, acc16[j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16[j], acc16[j], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         // keep each step's LDS prefetch and side work inside its own MFMA shadow
@@ -331,10 +338,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     int cur = 0;
     for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
 #if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
-        compute_chunk<C, false>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+        compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
                                 goff, woff_g, regs, acc, woff16, pixoff16, acc16);
 #else
-        compute_chunk<C, true>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+        compute_chunk<C, true, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
                                goff, woff_g, regs, acc, woff16, pixoff16, acc16);
 #endif
 #if !defined(MVLM_ABLATE_NO_BARRIER)
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
 #endif
         cur ^= 1;
     }
-    compute_chunk<C, false>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+    compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16);
 #if defined(MVLM_CONV_TIMING)
     const long long t_epi = clock64();
 #endif
@@ -375,6 +382,85 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         for (int w = 0; w < 3; ++w)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+    }
+
+    if constexpr (AMAX) {
+        // Fused heatmap argmax (paulsenpredictor.py:123) on the TRANSPOSED accumulators: conv11 has no residual /
+        // post-BN, so the heatmap value is acc + bias.  Lane (half, l31) owns output channel co0 + 32 m + l31 and, of
+        // every 32-pixel row segment n of its wave, the pixels x0 + (r & 3) + 8 (r >> 2) + 4 half: the maximum over a
+        // lane's pixels is a chain of compares on registers (np.argmax order through argmax_key: NaN = maximum,
+        // first maximum in row-major order wins), one exchange between the half-waves finishes a wave's partial.
+        const int W = a.W;
+        constexpr int ROWS_PER_WAVE = C::PIX_T / 4 / C::TW;  // = NT for the 32-pixel-row tiles
+        static_assert(C::TW == 32 && C::NIMG == 1 && ROWS_PER_WAVE == C::NT, "fused argmax expects 32-pixel row tiles");
+        const size_t part = size_t(a.amax_part0) + (size_t(ty) * tiles_x + tx) * 4 + wave;
+        auto pixel_index = [&](int y, int x) {
+            return a.up_out == 2 ? (2 * y + a.sub_y) * (2 * W) + 2 * x + a.sub_x : y * W + x;
+        };
+        static_for<0, C::MT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const int co = co0 + m * 32 + l31;
+            const float bias = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+            int best_k = int(0x807fffff);  // argmax_key(-inf)
+            int best_i = 0x7fffffff;
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n) {
+                const int y = y0 + wave * ROWS_PER_WAVE + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int k = argmax_key(acc[m][n][r] + bias);
+                    const int pix = pixel_index(y, x);
+                    const bool better = k > best_k;  // ascending pixel order within the lane: strict > keeps the first
+                    best_k = better ? k : best_k;
+                    best_i = better ? pix : best_i;
+                }
+            }
+            // the other half-wave holds the other pixels of the same channel
+            const int ok = __shfl_xor(best_k, 32), oi = __shfl_xor(best_i, 32);
+            if (ok > best_k || (ok == best_k && oi < best_i)) {
+                best_k = ok;
+                best_i = oi;
+            }
+            if (half == 0 && co < a.cout && b0 < a.B) {
+                const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + part;
+                a.amax_val[o] = argmax_value(best_k);
+                a.amax_idx[o] = best_i;
+            }
+        });
+        if constexpr (C::TAIL16) {
+            // strip (transposed 16x16x4 tiles): lane (q16, i16) owns channel co0 + 32 MT + i16 and the pixels
+            // 16 j + 4 q16 + i of its wave's pixel range
+            const int co = co0 + C::MT * 32 + i16;
+            const float bias = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+            int best_k = int(0x807fffff);
+            int best_i = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < C::NT16; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = wave * (C::PIX_T / 4) + j * 16 + 4 * q16 + i;
+                    const int k = argmax_key(acc16[j][i] + bias);
+                    const int pix = pixel_index(y0 + p / C::TW, x0 + p % C::TW);
+                    const bool better = k > best_k || (k == best_k && pix < best_i);
+                    best_k = better ? k : best_k;
+                    best_i = better ? pix : best_i;
+                }
+#pragma unroll
+            for (int s = 16; s <= 32; s <<= 1) {
+                const int ok = __shfl_xor(best_k, s), oi = __shfl_xor(best_i, s);
+                if (ok > best_k || (ok == best_k && oi < best_i)) {
+                    best_k = ok;
+                    best_i = oi;
+                }
+            }
+            if (q16 == 0 && co < a.cout && b0 < a.B) {
+                const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + part;
+                a.amax_val[o] = argmax_value(best_k);
+                a.amax_idx[o] = best_i;
+            }
+        }
+        return;
     }
 
     // ---------------------------------- epilogue ---------------------------------------
@@ -730,102 +816,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         }
     }
 
-    if constexpr (AMAX) {
-        // Fused heatmap argmax (paulsenpredictor.py:123): conv11 has no residual / post-BN, so
-        // the heatmap value is acc + bias.  First maximum in row-major order wins ties.
-        static_for<0, C::MT>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int coc = co < a.cout ? co : 0;
-                const float bias = a.bias ? a.bias[coc] : 0.f;
-                // value first: max over this lane's pixels, then over the 32 lanes of the half-wave with
-                // DPP-modified v_max (row_shr 1, 2, 4, 8 leave each 16-lane row's maximum in its lane 15,
-                // row_bcast15 hands it to the next row: lanes 31 / 63 hold the half-waves' maxima).  The values
-                // are compared as argmax_key integers, i.e. in np.argmax's order (NaN = maximum, +0 == -0)
-                int keys[C::NT];
-                int best_k = int(0x807fffff);  // argmax_key(-inf)
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n) {
-                    keys[n] = lane_ok[n] ? argmax_key(acc[m][n][r] + bias) : int(0x807fffff);
-                    best_k = max(best_k, keys[n]);
-                }
-                auto dpp_i = [](int x, auto ctrl_c, auto rows_c) {
-                    return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, decltype(rows_c)::value, 0xf, false);
-                };
-                using SHR1 = std::integral_constant<int, 0x111>;
-                using SHR2 = std::integral_constant<int, 0x112>;
-                using SHR4 = std::integral_constant<int, 0x114>;
-                using SHR8 = std::integral_constant<int, 0x118>;
-                using BC15 = std::integral_constant<int, 0x142>;
-                using ALL = std::integral_constant<int, 0xf>;
-                using ODD = std::integral_constant<int, 0xa>;
-                best_k = max(best_k, dpp_i(best_k, SHR1{}, ALL{}));
-                best_k = max(best_k, dpp_i(best_k, SHR2{}, ALL{}));
-                best_k = max(best_k, dpp_i(best_k, SHR4{}, ALL{}));
-                best_k = max(best_k, dpp_i(best_k, SHR8{}, ALL{}));
-                best_k = max(best_k, dpp_i(best_k, BC15{}, ODD{}));
-                const int m_lo = __builtin_amdgcn_readlane(best_k, 31);
-                const int m_hi = __builtin_amdgcn_readlane(best_k, 63);
-                best_k = half ? m_hi : m_lo;
-                const float best_v = argmax_value(best_k);
-                // then the first pixel (row-major) that attains it
-                int best_i = 0x7fffffff;
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n) best_i = min(best_i, keys[n] == best_k ? ppix[n] : 0x7fffffff);
-                best_i = min(best_i, dpp_i(best_i, SHR1{}, ALL{}));
-                best_i = min(best_i, dpp_i(best_i, SHR2{}, ALL{}));
-                best_i = min(best_i, dpp_i(best_i, SHR4{}, ALL{}));
-                best_i = min(best_i, dpp_i(best_i, SHR8{}, ALL{}));
-                best_i = min(best_i, dpp_i(best_i, BC15{}, ODD{}));
-                if (l31 == 31 && co < a.cout && b0 < a.B) {
-                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
-                    a.amax_val[o] = best_v;
-                    a.amax_idx[o] = best_i;
-                }
-            }
-        });
-        if constexpr (C::TAIL16) {
-            // strip: a 16-lane row holds 16 pixels of channels 4*q16 + i; rows reduce on their own
-            using SHR1 = std::integral_constant<int, 0x111>;
-            using SHR2 = std::integral_constant<int, 0x112>;
-            using SHR4 = std::integral_constant<int, 0x114>;
-            using SHR8 = std::integral_constant<int, 0x118>;
-            auto dpp_i = [](int x, auto ctrl_c) { return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl_c)::value, 0xf, 0xf, false); };
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int keys[C::NT16];
-                int best_k = int(0x807fffff);  // argmax_key(-inf)
-#pragma unroll
-                for (int j = 0; j < C::NT16; ++j) {
-                    keys[j] = argmax_key(val16[j][i]);
-                    best_k = max(best_k, keys[j]);
-                }
-                best_k = max(best_k, dpp_i(best_k, SHR1{}));
-                best_k = max(best_k, dpp_i(best_k, SHR2{}));
-                best_k = max(best_k, dpp_i(best_k, SHR4{}));
-                best_k = max(best_k, dpp_i(best_k, SHR8{}));  // lane 15 of every row: the row's maximum
-                const int r0 = __builtin_amdgcn_readlane(best_k, 15), r1 = __builtin_amdgcn_readlane(best_k, 31);
-                const int r2 = __builtin_amdgcn_readlane(best_k, 47), r3 = __builtin_amdgcn_readlane(best_k, 63);
-                best_k = q16 == 0 ? r0 : q16 == 1 ? r1 : q16 == 2 ? r2 : r3;
-                const float best_v = argmax_value(best_k);
-                int best_i = 0x7fffffff;
-#pragma unroll
-                for (int j = 0; j < C::NT16; ++j) best_i = min(best_i, keys[j] == best_k ? pix16[j] : 0x7fffffff);
-                best_i = min(best_i, dpp_i(best_i, SHR1{}));
-                best_i = min(best_i, dpp_i(best_i, SHR2{}));
-                best_i = min(best_i, dpp_i(best_i, SHR4{}));
-                best_i = min(best_i, dpp_i(best_i, SHR8{}));
-                const int co = co0 + C::MT * 32 + 4 * q16 + i;
-                if (i16 == 15 && co < a.cout && b0 < a.B) {
-                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + a.amax_part0 + (size_t(ty) * tiles_x + tx) * 4 + wave;
-                    a.amax_val[o] = best_v;
-                    a.amax_idx[o] = best_i;
-                }
-            }
-        }
-    }
 }
 
 // ---- variant table ---------------------------------------------------------------------
@@ -854,6 +844,7 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
         MVLM_REQUIRE(ctx, a.amax_part0 >= 0 && a.amax_part0 + tiles_x * tiles_y * 4 <= a.amax_parts,
                      "conv: argmax partial range mismatch");
         MVLM_REQUIRE(ctx, !a.res1 && !a.post_scale && a.up_out != 1, "conv: fused argmax expects a plain conv + bias layer");
+        MVLM_REQUIRE(ctx, !a.out && !a.out_raw && !a.pool_out, "conv: a fused-argmax launch does not materialise the heatmap");
     }
     const long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
