@@ -117,6 +117,16 @@ class Pipeline(abc.ABC):
             self._buffers[name] = buf
         return buf
 
+    def _buffer_bytes(self, name: str, n_bytes: int):
+        """A uint8 device buffer of at least this size that lives as long as the pipeline (8-byte aligned slices)."""
+        import torch
+
+        buf = self._buffers.get(name)
+        if buf is None or buf.numel() < n_bytes:
+            buf = torch.empty((n_bytes + 7) // 8 * 8, dtype=torch.uint8, device=torch.device("cuda", self.device))
+            self._buffers[name] = buf
+        return buf
+
     def _say(self, *a):
         if self.verbose:
             print(*a)
@@ -196,32 +206,26 @@ class Pipeline(abc.ABC):
 
         rot = view_rotations(transform_stack)  # once per call: renderer and estimator share it
         tm = self._timer
+        # Everything the host has to prepare goes first, while the stream is empty: a host-to-device copy from
+        # ordinary memory waits for the work enqueued before it, so uploads issued behind the network would stall
+        # the host until the network has finished and leave the GPU idle while the host catches up.
+        draws_fn = None
         if sharded:
-            # One RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) and broadcasts the
-            # [NL, 8] index table.  The table for the survivor counts the quantile filter is expected to yield is
-            # drawn and broadcast NOW, before this step's GPU work is enqueued (a collective behind the network
-            # would stall every rank's host until the network has finished); should the real counts differ (tied /
-            # NaN scores, absolute mode) rank 0 rewinds its RNG and the table is drawn and broadcast again.
-            nl_all = p2.get_lm_count()
-            spec = e3.expected_counts(nl_all, n_total)
+            # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) and broadcasts the table
             dev_t = torch.device("cuda", self.device)
-            pre = {"state": np.random.get_state() if rank == 0 else None, "draws": None}
-            if spec is not None:
-                quiet, e3.verbose = e3.verbose, False
-                try:
-                    first = e3.draw_ransac_indices(spec) if rank == 0 else None
-                finally:
-                    e3.verbose = quiet
-                pre["draws"] = parallel.broadcast_int32(first, (nl_all, 8), dev_t)
 
-            def sharded_draws(counts):
-                if pre["draws"] is not None and np.array_equal(counts, spec):
-                    return pre["draws"]
-                if rank == 0:
-                    np.random.set_state(pre["state"])
+            def draws_fn(counts):
                 draws = e3.draw_ransac_indices(counts) if rank == 0 else None
                 return parallel.broadcast_int32(draws, (len(counts), 8), dev_t)
 
+        nl_all = p2.get_lm_count()
+        plan = e3.plan_draws(nl_all, n_total, draws_fn)  # the RANSAC draws for the expected survivor counts, on the device
+        rot_dev = e3.upload_rotations(rot)
+        # landmarks f64[NL,3] | error f64[NL] | survivor counts i32[NL] in ONE buffer: one device-to-host copy per mesh
+        pack = self._buffer_bytes("result", nl_all * (24 + 8 + 4))
+        snap_view = pack[: nl_all * 24].view(torch.float64).view(nl_all, 3)
+        err_view = pack[nl_all * 24: nl_all * 32].view(torch.float64)
+        count_view = pack[nl_all * 32: nl_all * 36].view(torch.int32)
         with tm.stage("render"):
             # one image stack / maxima buffer per view count, reused from call to call: stable addresses let the
             # predictor replay its captured launch graph instead of re-enqueueing ~160 kernels per mesh
@@ -249,23 +253,24 @@ class Pipeline(abc.ABC):
                 torch.cuda.synchronize()
 
         with tm.stage("lines"):
-            starts, ends = e3.lines_device(maxima, transform_stack, 256, rot=rot)
+            starts, ends = e3.lines_device(maxima, transform_stack, 256, rot_dev=rot_dev)
 
         with tm.stage("consensus"):
-            draws_fn = None
-            if sharded:
-                draws_fn = sharded_draws
             if self.visualize_rays:
                 self._rays = (mesh, starts.cpu().numpy(), ends.cpu().numpy())
-            out, err, verify = e3.consensus_device(maxima, starts, ends, draws_fn=draws_fn, deferred=True)
+            out, err, verify = e3.consensus_device(maxima, starts, ends, deferred=True, plan=plan, err_out=err_view,
+                                                   count_out=count_view)
 
         with tm.stage("project"):
-            # the snap is enqueued before anything is fetched: one wait per mesh, at the end
-            snapped = e3.project_device(mesh, out)
-            if verify():  # the RANSAC draws had to be repeated for other survivor counts (tied / NaN scores)
-                snapped = e3.project_device(mesh, out)
-            landmarks = snapped.cpu().numpy()
-            error = e3.mean_error(err.cpu().numpy())
+            # the snap is enqueued before anything is fetched: one wait and one copy per mesh, at the end
+            e3.project_device(mesh, out, out=snap_view)
+            host = pack.cpu().numpy()
+            if verify(counts=host[nl_all * 32: nl_all * 36].view(np.int32)):
+                # the RANSAC draws had to be repeated for other survivor counts (tied / NaN scores, absolute mode)
+                e3.project_device(mesh, out, out=snap_view)
+                host = pack.cpu().numpy()
+            landmarks = host[: nl_all * 24].view(np.float64).reshape(nl_all, 3).copy()
+            error = e3.mean_error(host[nl_all * 24: nl_all * 32].view(np.float64))
             r3.check()  # deferred renderer status (the .cpu() above already synchronised)
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error

@@ -40,11 +40,18 @@ class HipEstimator3D:
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         return torch, dev
 
-    def lines_device(self, landmarks_dev, transform_stack, image_size: int = 256, rot: np.ndarray | None = None):
+    def upload_rotations(self, rot: np.ndarray):
+        """[N,9] float64 view rotations -> device tensor.  A host-to-device copy from ordinary memory waits for the
+        work already enqueued on the stream, so the pipeline does this before it enqueues the step's GPU work."""
+        torch, dev = self._torch()
+        return torch.from_numpy(np.ascontiguousarray(rot, dtype=np.float64)).to(dev)
+
+    def lines_device(self, landmarks_dev, transform_stack, image_size: int = 256, rot: np.ndarray | None = None,
+                     rot_dev=None):
         """maxima f32[NL,N,3] on device + host poses -> (starts, ends) f64[NL,N,3] on device."""
         torch, dev = self._torch()
         nl, n = int(landmarks_dev.shape[0]), int(landmarks_dev.shape[1])
-        rot = torch.from_numpy(np.ascontiguousarray(view_rotations(transform_stack) if rot is None else rot)).to(dev)
+        rot = rot_dev if rot_dev is not None else self.upload_rotations(view_rotations(transform_stack) if rot is None else rot)
         starts = torch.empty((nl, n, 3), dtype=torch.float64, device=dev)
         ends = torch.empty_like(starts)
         self.ctx.check(self.ctx.lib.mvlm_estimate_lines(
@@ -76,60 +83,82 @@ class HipEstimator3D:
         k = n_views - 1 - int(np.floor(float(self.threshold_quantile) * (n_views - 1)))
         return np.full(n_landmarks, k, dtype=np.int32)
 
-    def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None, deferred: bool = False):
+    def plan_draws(self, n_landmarks: int, n_views: int, draws_fn=None):
+        """Make the RANSAC draws of the coming consensus BEFORE the step's GPU work is enqueued, where that is
+        possible, and put them on the device.  The draws need each landmark's survivor count k (the reference draws
+        from range(k), estimator3d.py:105), which only exists once the network has finished; fetching it, drawing
+        (~0.3 ms of numpy calls) and uploading the table at that point leaves the GPU idle in the middle of the step.
+        In quantile mode k is known beforehand unless scores tie or are NaN (``expected_counts``), so the table is
+        drawn for that k now; ``consensus_device(plan=...)`` enqueues the solve with it and its ``verify`` compares
+        the real counts afterwards - a mismatch rewinds the global RNG to the state saved here and repeats draws +
+        solve, so the stream of random numbers consumed, and every result, is the one the synchronous order gives.
+        Returns a dict (``expected`` is None when nothing could be planned: absolute mode)."""
+        torch, dev = self._torch()
+        plan = {"expected": self.expected_counts(n_landmarks, n_views), "rng_state": np.random.get_state(),
+                "draws_fn": draws_fn, "draws_dev": None}
+        if plan["expected"] is not None:
+            verbose, self.verbose = self.verbose, False  # "Not enough points" is reported by the pass that counts
+            try:
+                draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(plan["expected"]), dtype=np.int32)
+            finally:
+                self.verbose = verbose
+            if draws.shape != (n_landmarks, 8):
+                raise ValueError(f"RANSAC draws must be [{n_landmarks}, 8], got {draws.shape}")
+            plan["draws_dev"] = torch.from_numpy(draws).to(dev)
+        return plan
+
+    def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None, deferred: bool = False, plan=None,
+                         err_out=None, count_out=None):
         """Filter + one-shot RANSAC + LSQ on device.  ``draws_fn(counts) -> int32[NL,8]`` replaces the local
         RNG draw (the sharded pipeline broadcasts rank 0's).  Returns (landmarks f64[NL,3] tensor,
         per-landmark error f64[NL] tensor, counts int32[NL] numpy).
 
         ``deferred=True`` returns ``(landmarks, error, verify)`` instead and does not wait for the GPU:
-        ``verify()`` - to be called once, after the caller has enqueued whatever consumes the landmarks - fetches
-        the survivor counts, and if the draws were made for other counts (see below) repeats them and the solve
-        IN PLACE and returns True: the caller must then redo the work it had enqueued on the landmarks."""
+        ``verify(counts=None)`` - to be called once, after the caller has enqueued whatever consumes the landmarks -
+        takes (or fetches) the survivor counts, and if the draws were made for other counts (``plan_draws``) repeats
+        them and the solve IN PLACE and returns True: the caller must then redo the work it had enqueued on the
+        landmarks.  ``plan``: the result of ``plan_draws`` made before the step's GPU work (default: planned here).
+        ``err_out`` / ``count_out``: device tensors (f64[NL] / i32[NL]) to write into, e.g. views of one buffer the
+        caller fetches with a single copy."""
         torch, dev = self._torch()
         if self.mode not in _MODES:
             raise ValueError(f"Unknown mode for line matching in Estimator: {self.mode}")
         nl, n = int(landmarks_dev.shape[0]), int(landmarks_dev.shape[1])
         mask = torch.empty((nl, n), dtype=torch.uint8, device=dev)
-        count = torch.empty((nl,), dtype=torch.int32, device=dev)
+        count = count_out if count_out is not None else torch.empty((nl,), dtype=torch.int32, device=dev)
         self.ctx.check(self.ctx.lib.mvlm_consensus_mask(
             self.ctx.handle, C.c_void_p(landmarks_dev.data_ptr()), n, nl, _MODES[self.mode],
             float(self.threshold_quantile), float(self.threshold_absolute), C.c_void_p(mask.data_ptr()),
             C.c_void_p(count.data_ptr())), ValueError)
         out = torch.empty((nl, 3), dtype=torch.float64, device=dev)
-        err = torch.empty((nl,), dtype=torch.float64, device=dev)
+        err = err_out if err_out is not None else torch.empty((nl,), dtype=torch.float64, device=dev)
+        if plan is None:
+            plan = self.plan_draws(nl, n, draws_fn)
+        draws_fn = plan["draws_fn"]
 
-        def solve(counts_for_draws):
-            draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(counts_for_draws), dtype=np.int32)
-            if draws.shape != (nl, 8):
-                raise ValueError(f"RANSAC draws must be [{nl}, 8], got {draws.shape}")
-            draws_dev = torch.from_numpy(draws).to(dev, non_blocking=True)
+        def solve(draws_dev):
             self.ctx.check(self.ctx.lib.mvlm_consensus_solve(
                 self.ctx.handle, C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()), C.c_void_p(mask.data_ptr()),
                 C.c_void_p(count.data_ptr()), C.c_void_p(draws_dev.data_ptr()), n, nl, C.c_void_p(out.data_ptr()),
                 C.c_void_p(err.data_ptr())))
 
-        # The draws need each landmark's survivor count k (the reference draws from range(k), estimator3d.py:105),
-        # which only exists once the network has finished: waiting for it stalls the host in the middle of the
-        # step.  In quantile mode k is known beforehand unless scores tie or are NaN: "value > np.quantile(values,
-        # q)" keeps N - 1 - floor(q (N - 1)) of N distinct values.  So the draws are made for that k while the GPU
-        # is still busy, the solve is enqueued behind the filter, and the real counts are compared afterwards; a
-        # mismatch rewinds the global RNG and repeats draws + solve with the real counts, so the stream of random
-        # numbers consumed - and every result - is the one the synchronous order gives.
-        expected = self.expected_counts(nl, n)
-        state = {"counts": None}
-        if expected is not None:
-            rng_state = np.random.get_state()
-            verbose, self.verbose = self.verbose, False  # "Not enough points" is reported by the pass that counts
-            try:
-                solve(expected)
-            finally:
-                self.verbose = verbose
+        def draw_and_solve(counts):
+            draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(counts), dtype=np.int32)
+            if draws.shape != (nl, 8):
+                raise ValueError(f"RANSAC draws must be [{nl}, 8], got {draws.shape}")
+            keep = torch.from_numpy(draws).to(dev)
+            solve(keep)
 
-            def verify() -> bool:
-                counts = state["counts"] = count.cpu().numpy()
+        state = {"counts": None}
+        expected = plan["expected"]
+        if expected is not None and len(expected) == nl and plan["draws_dev"] is not None:
+            solve(plan["draws_dev"])
+
+            def verify(counts=None) -> bool:
+                counts = state["counts"] = np.asarray(count.cpu().numpy() if counts is None else counts)
                 if not np.array_equal(counts, expected):
-                    np.random.set_state(rng_state)
-                    solve(counts)
+                    np.random.set_state(plan["rng_state"])
+                    draw_and_solve(counts)
                     return True
                 if self.verbose and expected[0] < 3:
                     for lm in range(nl):
@@ -137,19 +166,19 @@ class HipEstimator3D:
                 return False
         else:
             state["counts"] = count.cpu().numpy()
-            solve(state["counts"])
+            draw_and_solve(state["counts"])
 
-            def verify() -> bool:
+            def verify(counts=None) -> bool:
                 return False
         if deferred:
             return out, err, verify
         verify()
-        counts = state["counts"]
-        return out, err, counts
+        return out, err, state["counts"]
 
-    def project_device(self, mesh: Mesh, landmarks_dev):
+    def project_device(self, mesh: Mesh, landmarks_dev, out=None):
         torch, dev = self._torch()
-        out = torch.empty_like(landmarks_dev)
+        if out is None:
+            out = torch.empty_like(landmarks_dev)
         handle = upload_mesh(self.ctx, mesh)
         self.ctx.check(self.ctx.lib.mvlm_project_to_surface(self.ctx.handle, handle, C.c_void_p(landmarks_dev.data_ptr()),
                                                             int(landmarks_dev.shape[0]), C.c_void_p(out.data_ptr())))
