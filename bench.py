@@ -192,6 +192,7 @@ def main():
                          "slower than the replayed launch graph the product runs); default: time the product path and "
                          "record the events over the same number of steps right after the timed region")
     ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
+    ap.add_argument("--cnn-execution", default="", help=argparse.SUPPRESS)  # "graphs,concurrency" for experiments, e.g. "1,0"
     ap.add_argument("--cpu-views", type=int, default=-1, help="views in the CPU-baseline sample (-1 = the whole workload, at most 96; 0 = skip)")
     args = ap.parse_args()
 
@@ -267,6 +268,9 @@ def main():
         np.random.seed(1)
         return pipe.predict_mesh_device(mesh, poses)
 
+    if args.cnn_execution and not fusion_only:
+        g, cc = (int(v) for v in args.cnn_execution.split(","))
+        pipe.predictor_2d.set_execution(graphs=bool(g), concurrency=cc)
     cnn_ctx = None if fusion_only else pipe.predictor_2d.ctx
     r_ctx = pipe.renderer_3d.ctx
     for _ in range(args.warmup):

@@ -112,8 +112,8 @@ int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const
                       float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch);
 /* How the ~160 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
  * shapes is captured as a hipGraph the second time it is seen and replayed afterwards; 0: always launch by
- * launch.  concurrency 1 (default): for batches of <= 32 views the lower hourglass pyramid runs on a second
- * stream beside the 128x128 / 64x64 skip blocks; 0: one stream.  Results are identical in every mode.
+ * launch.  concurrency 1: for batches of <= 32 views the lower hourglass pyramid runs on a second stream
+ * beside the 128x128 / 64x64 skip blocks; 0 (default): one stream.  Results are identical in every mode.
  * mvlm_cnn_execution_stats reports how many passes ran eagerly / were captured / replayed, and how many
  * captures failed (those passes ran eagerly instead). */
 int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency);
@@ -139,6 +139,8 @@ int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, in
                 const float* post_scale_host, const float* post_shift_host, const float* r_dev, int upsample_in,
                 float* y_dev);
 
+/* test hook: mvlm_conv2d on this ctx runs kernel variant `variant` (ids of mvlm_conv_variant_name; -1 = automatic) */
+int mvlm_conv_force_variant(mvlm_ctx* ctx, int variant);
 /* kernel-variant timing for tools/tune_conv.py: `iters` launches of one layer shape on zero data with kernel
  * variant `variant` (< 0: the dispatcher's choice, reported in *variant_used); flags: 1 pre-BN+ReLU, 2 residual
  * add + raw copy, 4 bias, 8 post-BN+ReLU.  Fails for shapes the variant cannot serve. */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mvlm_heatmap_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mvlm_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int,
                               c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvlm_conv_force_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_conv_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   c_float_p, C.POINTER(C.c_int)]),
     "mvlm_estimate_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

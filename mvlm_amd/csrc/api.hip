@@ -150,6 +150,13 @@ extern "C" void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* m) {
     delete m;
 }
 
+// test / tuning hook: the next mvlm_conv2d calls on this ctx use exactly this kernel variant (-1: the dispatcher's choice)
+extern "C" int mvlm_conv_force_variant(mvlm_ctx* ctx, int variant) {
+    MVLM_ENTER(ctx);
+    ctx->conv_force_variant = variant < 0 ? -1 : variant;
+    return 0;
+}
+
 // ---- single convolution (test hook): packs the weights like mvlm_amd/weights.py does -------
 extern "C" int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host,
                            int cout, int ksize, const float* bias_host, const float* pre_scale_host,

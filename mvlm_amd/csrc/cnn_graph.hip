@@ -108,9 +108,15 @@ struct Exec {
     void fork() {
         forked = true;
         if (dry || rc) return;
-        if (!st.side_stream && hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking) != hipSuccess) {
-            rc = ctx->fail("cnn: hipStreamCreate failed");
-            return;
+        if (!st.side_stream) {
+            // highest priority: the side stream carries the chain of short launches; whenever a workgroup slot
+            // frees up under the main stream's big launches, the chain's workgroups should get it first
+            int lo_prio = 0, hi_prio = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+            if (hipStreamCreateWithPriority(&st.side_stream, hipStreamNonBlocking, hi_prio) != hipSuccess) {
+                rc = ctx->fail("cnn: hipStreamCreate failed");
+                return;
+            }
         }
         hipEvent_t e = next_event();
         if (rc) return;
@@ -290,9 +296,12 @@ struct Exec {
         auto R = [&](int i) { return rb0 + i - 1; };
         // Small batches: the 32x32 .. 4x4 levels are a chain of ~60 short, latency-bound launches on few
         // workgroups.  They only depend on low1's pooled copy, and the 128x128 / 64x64 skip blocks (up1, up11)
-        // do not depend on them, so the chain runs on the side stream beside those big launches.  Large
-        // batches fill the chip with every launch; there the order stays sequential.
-        const bool concurrent = st.concurrency != 0 && long(B) * 32 * 32 <= CONCURRENT_MAX_PIXELS_32;
+        // do not depend on them, so the chain CAN run on the side stream beside those big launches
+        // (mvlm_cnn_set_execution, concurrency = 1; off by default: measured on the MI355X the chain's workgroups
+        // either wait for a CU the big launch has filled or, where they fit beside it, crawl behind its matrix
+        // work - DESIGN.md 4.1).  Large batches fill the chip with every launch; there the order is sequential.
+        const bool small_batch = long(B) * 32 * 32 <= CONCURRENT_MAX_PIXELS_32;
+        const bool concurrent = st.concurrency != 0 && small_batch;
         Tensor lowt11, lowt12, lowt13, lowt14;
         Tensor low1 = rb(R(2), x_pooled, nullptr, &lowt11);
         if (concurrent) {

@@ -140,7 +140,7 @@ struct CnnState {
     std::vector<hipEvent_t> sync_events;
     size_t sync_cursor = 0;
     int graph_mode = 1;            // 0: always eager, 1: replay captured graphs when not profiling
-    int concurrency = 1;           // 0: one stream, 1: lower hourglass pyramid on the side stream (small batches)
+    int concurrency = 0;           // 0: one stream (default), 1: lower hourglass pyramid on a side stream (small batches)
     std::vector<CnnGraphEntry> graphs;
     long graph_replays = 0, graph_captures = 0, eager_runs = 0, graph_failures = 0;
 };

@@ -81,7 +81,8 @@ int pick_variant_rules(const ConvArgs& a) {
 // only - the fused argmax / upsampling launches have one kernel that can serve them), the rules otherwise.
 int pick_variant(const ConvArgs& a, bool rules_only = false) {
     const int by_rule = pick_variant_rules(a);
-    if (rules_only || MVLM_CONV_TUNED_N == 0 || a.amax_val || a.up_in || a.up_out == 2 || a.ksize == 2 || a.H != a.W) return by_rule;
+    if (rules_only || MVLM_CONV_TUNED_N == 0 || a.amax_val || a.up_in || a.up_out == 2 || a.ksize == 2 || a.H != a.W)
+        return by_rule;
     const ConvTuned key = {short(a.ksize), short(a.cin_pad), short(a.cout_pad), short(a.H), short(a.B > 32767 ? 32767 : a.B), 0};
     auto less = [](const ConvTuned& x, const ConvTuned& y) {
         if (x.ksize != y.ksize) return x.ksize < y.ksize;

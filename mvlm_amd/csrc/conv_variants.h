@@ -30,7 +30,19 @@
     X(13, "conv3x3_sk_t4x8", Cfg<32, 8, 4, 1, 3, 32, true>) \
     X(14, "conv3x3_sk_t4x4x2", Cfg<32, 4, 4, 2, 3, 32, true>) \
     X(15, "conv3x3_sk_t1x32", Cfg<32, 32, 1, 1, 3, 32, true>)
+// split-K tiles with 16- and 8-channel chunks: 49 / 26 KB of LDS instead of 94 KB - three or more workgroups per CU
+// and a shorter first-chunk prologue for the latency-bound launches of the small hourglass levels
+#define MVLM_CONV_VARIANTS_G10(X) \
+    X(18, "conv3x3_sk16_t2x16", Cfg<32, 16, 2, 1, 3, 16, true>) \
+    X(19, "conv3x3_sk16_t4x8", Cfg<32, 8, 4, 1, 3, 16, true>) \
+    X(20, "conv3x3_sk16_t4x4x2", Cfg<32, 4, 4, 2, 3, 16, true>) \
+    X(21, "conv3x3_sk16_t1x32", Cfg<32, 32, 1, 1, 3, 16, true>)
+#define MVLM_CONV_VARIANTS_G11(X) \
+    X(22, "conv3x3_sk8_t2x16", Cfg<32, 16, 2, 1, 3, 8, true>) \
+    X(23, "conv3x3_sk8_t4x8", Cfg<32, 8, 4, 1, 3, 8, true>) \
+    X(24, "conv3x3_sk8_t4x4x2", Cfg<32, 4, 4, 2, 3, 8, true>) \
+    X(25, "conv3x3_sk8_t1x32", Cfg<32, 32, 1, 1, 3, 8, true>)
 #define MVLM_CONV_VARIANTS(X) \
-    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X)
-#define MVLM_CONV_N_GROUPS 10
+    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X)
+#define MVLM_CONV_N_GROUPS 12
 #endif

@@ -219,7 +219,8 @@ class Pipeline(abc.ABC):
                 return parallel.broadcast_int32(draws, (len(counts), 8), dev_t)
 
         nl_all = p2.get_lm_count()
-        plan = e3.plan_draws(nl_all, n_total, draws_fn)  # the RANSAC draws for the expected survivor counts, on the device
+        # sharded: the draws come out of a collective, which must not queue up behind this step's network
+        plan = e3.plan_draws(nl_all, n_total, draws_fn) if sharded else None
         rot_dev = e3.upload_rotations(rot)
         # landmarks f64[NL,3] | error f64[NL] | survivor counts i32[NL] in ONE buffer: one device-to-host copy per mesh
         pack = self._buffer_bytes("result", nl_all * (24 + 8 + 4))
@@ -251,6 +252,11 @@ class Pipeline(abc.ABC):
                 maxima = parallel.all_gather_views(maxima, n_total)
             if self.verbose:
                 torch.cuda.synchronize()
+
+        if plan is None:
+            # the RANSAC draws for the expected survivor counts (~0.3 ms of numpy calls) are made now, while the GPU
+            # works on the views; they travel through pinned memory on a copy stream of their own
+            plan = e3.plan_draws(nl_all, n_total, None)
 
         with tm.stage("lines"):
             starts, ends = e3.lines_device(maxima, transform_stack, 256, rot_dev=rot_dev)

@@ -163,7 +163,7 @@ class HipPaulsenModel(Predictor2D):
                 maxima[:, s:s + nb] = part
         return maxima
 
-    def set_execution(self, graphs: bool = True, concurrency: bool = True):
+    def set_execution(self, graphs: bool = True, concurrency: bool = False):
         """How the forward pass is issued (mvlm_cnn_set_execution): replayed hipGraphs / launch by launch, and
         whether small batches run the lower hourglass pyramid on a second stream.  Results do not depend on it."""
         self.ctx.check(self.ctx.lib.mvlm_cnn_set_execution(self.ctx.handle, int(bool(graphs)), int(bool(concurrency))))

@@ -31,6 +31,8 @@ class HipEstimator3D:
         self.threshold_absolute = threshold_absolute
         self.verbose = verbose
         self.ctx = _lib.get_context(device)
+        self._upload_stream = None
+        self._draw_bufs: dict = {}
 
     # ---- helpers ----------------------------------------------------------------------
     def _torch(self):
@@ -95,7 +97,7 @@ class HipEstimator3D:
         Returns a dict (``expected`` is None when nothing could be planned: absolute mode)."""
         torch, dev = self._torch()
         plan = {"expected": self.expected_counts(n_landmarks, n_views), "rng_state": np.random.get_state(),
-                "draws_fn": draws_fn, "draws_dev": None}
+                "draws_fn": draws_fn, "draws_dev": None, "ready": None}
         if plan["expected"] is not None:
             verbose, self.verbose = self.verbose, False  # "Not enough points" is reported by the pass that counts
             try:
@@ -104,7 +106,23 @@ class HipEstimator3D:
                 self.verbose = verbose
             if draws.shape != (n_landmarks, 8):
                 raise ValueError(f"RANSAC draws must be [{n_landmarks}, 8], got {draws.shape}")
-            plan["draws_dev"] = torch.from_numpy(draws).to(dev)
+            # pinned staging buffer + a copy stream of its own: the upload neither waits for the work already
+            # enqueued on the compute stream nor blocks the host; the solve waits for the event
+            if self._upload_stream is None:
+                self._upload_stream = torch.cuda.Stream(device=dev)
+            key = (n_landmarks,)
+            bufs = self._draw_bufs.get(key)
+            if bufs is None:
+                bufs = self._draw_bufs[key] = (torch.empty((n_landmarks, 8), dtype=torch.int32).pin_memory(),
+                                               torch.empty((n_landmarks, 8), dtype=torch.int32, device=dev),
+                                               torch.cuda.Event())
+            pinned, dev_buf, event = bufs
+            event.synchronize()  # the previous upload out of this staging buffer has completed
+            pinned.copy_(torch.from_numpy(draws))
+            with torch.cuda.stream(self._upload_stream):
+                dev_buf.copy_(pinned, non_blocking=True)
+                event.record(self._upload_stream)
+            plan["draws_dev"], plan["ready"] = dev_buf, event
         return plan
 
     def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None, deferred: bool = False, plan=None,
@@ -152,6 +170,8 @@ class HipEstimator3D:
         state = {"counts": None}
         expected = plan["expected"]
         if expected is not None and len(expected) == nl and plan["draws_dev"] is not None:
+            if plan["ready"] is not None:
+                torch.cuda.current_stream(dev).wait_event(plan["ready"])
             solve(plan["draws_dev"])
 
             def verify(counts=None) -> bool:

@@ -367,3 +367,35 @@ def test_fused_argmax_nan_plane_like_numpy():
         assert np.isnan(got[lm, :, 2]).all()
     keep = [i for i in range(73) if i not in (3, 70)]
     np.testing.assert_array_equal(got[keep], clean[keep])
+
+
+# ---- every split-K tile variant (32-, 16- and 8-channel chunks) against torch -------------------------------
+@pytest.mark.parametrize("variant,size", [(12, 16), (13, 8), (14, 4), (15, 32), (18, 16), (19, 8), (20, 4), (21, 32),
+                                          (22, 16), (23, 8), (24, 4), (25, 32), (19, 32), (23, 16), (18, 32), (22, 64)])
+def test_split_k_variants_match_torch(variant, size):
+    """The tuned table may pick any split-K tile for a small level; each one forced onto a residual-block shaped
+    layer (pre-BN, residual add, ragged batch) against torch float64."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    cin, cout, batch = 128, 64, 5
+    rs = np.random.RandomState(variant * 31 + size)
+    x = rs.standard_normal((batch, cin, size, size)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32))
+    res = rs.standard_normal((batch, cout, size, size)).astype(np.float32)
+    xd, rd = dev(x), dev(res)
+    yd = torch.empty((batch, cout, size, size), dtype=torch.float32, device="cuda")
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    name = ctx.lib.mvlm_conv_variant_name(variant).decode()
+    assert name.startswith("conv3x3_sk"), name
+    ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, variant))
+    try:
+        ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
+                                      p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())))
+    finally:
+        ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, -1))
+    t = torch.relu(torch.from_numpy(x).double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
+                   + torch.from_numpy(pre[1]).double()[None, :, None, None])
+    want = (torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None, 1, 1) + torch.from_numpy(res).double()).numpy()
+    assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
