@@ -192,6 +192,8 @@ def main():
                          "slower than the replayed launch graph the product runs); default: time the product path and "
                          "record the events over the same number of steps right after the timed region")
     ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra pass that measures the opt-in fast precision")
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast"], help=argparse.SUPPRESS)  # experiments: time the fast path as the main loop
     ap.add_argument("--cnn-execution", default="", help=argparse.SUPPRESS)  # "graphs,concurrency" for experiments, e.g. "1,0"
     ap.add_argument("--cpu-views", type=int, default=-1, help="views in the CPU-baseline sample (-1 = the whole workload, at most 96; 0 = skip)")
     args = ap.parse_args()
@@ -271,6 +273,9 @@ def main():
     if args.cnn_execution and not fusion_only:
         g, cc = (int(v) for v in args.cnn_execution.split(","))
         pipe.predictor_2d.set_execution(graphs=bool(g), concurrency=cc)
+    if args.precision == "fast" and not fusion_only:
+        pipe.predictor_2d.set_precision("fast")
+        args.no_fast_mode = True
     cnn_ctx = None if fusion_only else pipe.predictor_2d.ctx
     r_ctx = pipe.renderer_3d.ctx
     for _ in range(args.warmup):
@@ -330,6 +335,52 @@ def main():
     set_profiling(0)
     render_ms, render_calls = render_ms[0], render_calls[0]
     exec_stats = None if fusion_only else pipe.predictor_2d.execution_stats()
+
+    # ---- opt-in "fast" precision (bf16x3 split, mvlm_amd/csrc/conv_fast.hip): a separate figure, never `value` ----------
+    fast_mode = None
+    if world == 1 and not fusion_only and not args.no_fast_mode:
+        p2 = pipe.predictor_2d
+        lm_exact, _ = step()
+        images = pipe._buffers["images"]
+        max_exact = p2.predict_device(images).clone()
+        p2.set_precision("fast")
+        try:
+            for _ in range(3):  # launch by launch, capture, first replay
+                step()
+            barrier()
+            tf0 = time.perf_counter()
+            for _ in range(args.steps):
+                lm_fast, _ = step()
+            barrier()
+            t_fast = (time.perf_counter() - tf0) / args.steps
+            max_fast = p2.predict_device(images)
+            differ = int((~torch.all(max_fast[:, :, :2] == max_exact[:, :, :2], dim=2)).sum().item())
+            fast_prof = {}
+            set_profiling(1)
+            step()
+            n = cnn_ctx.lib.mvlm_cnn_get_profile(cnn_ctx.handle, slot, var, fl, ms, cap)
+            for i in range(max(n, 0)):
+                q = fast_prof.setdefault(var[i], [0.0, 0.0, 0])
+                q[0] += fl[i]
+                q[1] += ms[i]
+                q[2] += 1
+            r_ctx.lib.mvlm_render_get_profile(r_ctx.handle, rv, rverts, rtris, rms, 64)
+            set_profiling(0)
+        finally:
+            p2.set_precision("exact")
+        if rank == 0:
+            log("fast precision, conv kernels of one step:")
+            for k, (f, t_ms, cnt) in sorted(fast_prof.items(), key=lambda kv: -kv[1][1]):
+                log(f"  {cnn_ctx.lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt:3d}  {t_ms:8.3f} ms/step  "
+                    f"{f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s (fp32-equivalent)")
+        fk = fast_prof.get(62)
+        fast_mode = {"value": round(n_total / t_fast, 2), "unit": "views/s", "ms_per_step": round(1e3 * t_fast, 3),
+                     "arithmetic": "opt-in: 3x3 layers with >= 16 input and >= 64 output channels on bf16x3-split operands "
+                                   "(6 of 9 cross products, v_mfma_f32_32x32x16_bf16, fp32 accumulate); everything else exact fp32",
+                     "argmax_planes_differing_from_exact": differ, "argmax_planes": int(max_exact.shape[0] * max_exact.shape[1]),
+                     "max_landmark_deviation_vs_exact_model_units": round(float(np.abs(lm_fast - lm_exact).max()), 6),
+                     "fast_kernel_launches_per_step": fk[2] if fk else 0,
+                     "fast_kernel_fp32_equivalent_tflops": round(fk[0] / (fk[1] * 1e-3) / 1e12, 1) if fk else None}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -405,7 +456,7 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32" if not fusion_only else "f64",
+            "dtype": ("f32" if args.precision == "exact" else "bf16x3 (opt-in fast precision: NOT the exact path)") if not fusion_only else "f64",
             "data": "synthetic",
             "config": {"workload": f"{what}: {n_total} views @ 256x256 of one {mesh.n_tris}-triangle textured synthetic "
                                    f"face OBJ, {nl} landmarks" + ("" if fusion_only else f", {c} input channels ({spec['mode']}), seeded random weights"),
@@ -420,6 +471,7 @@ def main():
             "kernel_events": "HIP events live over the timed steps" if profile_in_timed else
                              "HIP events over the same number of steps run right after the timed region (timed steps = product path, replayed launch graphs)",
             "cnn_execution": exec_stats,
+            "fast_mode": fast_mode,
             "cpu_baseline": cpu,
             "with_ingest": ingest,
         }

@@ -119,6 +119,21 @@ int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const
 int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency);
 int mvlm_cnn_execution_stats(mvlm_ctx* ctx, int64_t* eager_runs, int64_t* graph_captures, int64_t* graph_replays,
                              int64_t* graph_failures);
+/* OPT-IN reduced-cost arithmetic ("fast" precision, mvlm_amd/csrc/conv_fast.hip): the big 3x3 layers (input channels a
+ * multiple of 16, output channels of 64, 32-pixel rows) multiply bf16x3-split operands on the bf16 matrix cores - 6 of the 9
+ * cross products, fp32 accumulation - at 6/16 of the exact path's matrix time.  Results are fp32-accurate but NOT bit-identical
+ * to the exact path (argmax near-ties can flip); the default and every parity claim is the exact path.
+ *   mvlm_pack_fast_weights: host; w f32[cout][cin][3][3] -> u16 [cin_pad/16][3][3][2][3][cout_pad][8]; returns the element
+ *     count (out == NULL: only the count).
+ *   mvlm_cnn_load_fast: after mvlm_cnn_load; one blob of packed layers, slot_offsets[n_slots] = u16 offset per conv slot or -1.
+ *   mvlm_cnn_set_precision: 0 exact (default), 1 fast.
+ *   mvlm_conv2d_fast: test hook like mvlm_conv2d (3x3 only). */
+size_t mvlm_pack_fast_weights(const float* w, int cout, int cin, int cout_pad, int cin_pad, uint16_t* out);
+int mvlm_cnn_load_fast(mvlm_ctx* ctx, const uint16_t* blob_host, size_t n_u16, const int64_t* slot_offsets, int n_slots);
+int mvlm_cnn_set_precision(mvlm_ctx* ctx, int fast);
+int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
+                     const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
+                     const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev);
 /* per-kernel timing of the last mvlm_cnn_* call when profiling is on: fills up to
  * `cap` records of {slot, kernel_variant, flops, ms}; returns the record count. */
 int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled);

@@ -47,6 +47,7 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
     for (auto& kv : ctx->scratch)
         if (kv.second.first) hipFree(kv.second.first);
     if (ctx->cnn.blob) hipFree(ctx->cnn.blob);
+    if (ctx->cnn.fast_blob) hipFree(ctx->cnn.fast_blob);
     for (auto& e : ctx->mesh_pool) hipFree(e.first);
     if (ctx->render_overflow_host) hipHostFree(ctx->render_overflow_host);
     for (auto e : ctx->cnn.event_pool)

@@ -188,7 +188,13 @@ struct Exec {
             st.event_cursor += 2;
             hipEventRecord(e0, ctx->cur_stream());
         }
-        if (mvlm_launch_conv(ctx, a, &variant)) return rc = 1;
+        const bool fast = st.fast && size_t(slot) < st.fast_off.size() && st.fast_off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a);
+        if (fast) {
+            variant = MVLM_CONV_VARIANT_FAST;
+            if (mvlm_launch_conv_fast(ctx, a, st.fast_blob + st.fast_off[size_t(slot)])) return rc = 1;
+        } else if (mvlm_launch_conv(ctx, a, &variant)) {
+            return rc = 1;
+        }
         if (st.profiling) {
             hipEventRecord(e1, ctx->cur_stream());
             const double flops = 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(S) * S * B;
@@ -276,6 +282,7 @@ struct Exec {
 
     // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
     bool pool_fusable(int slot, const Tensor& x, ConvArgs a, int S) {
+        if (st.fast) return false;  // the bf16x3 kernel has no pooled output: the pool kernel follows the block
         const int32_t* r = d(slot);
         a.cin = r[1];
         a.cout = r[2];
@@ -635,6 +642,12 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
         st.blob = nullptr;
     }
     st.loaded = false;
+    st.fast = 0;
+    st.fast_off.clear();
+    if (st.fast_blob) {
+        (void)hipFree(st.fast_blob);
+        st.fast_blob = nullptr;
+    }
     for (auto& g : st.graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);  // captured launches point into the old weight blob
     st.graphs.clear();
@@ -709,6 +722,48 @@ extern "C" int mvlm_cnn_execution_stats(mvlm_ctx* ctx, int64_t* eager_runs, int6
     if (graph_captures) *graph_captures = st.graph_captures;
     if (graph_replays) *graph_replays = st.graph_replays;
     if (graph_failures) *graph_failures = st.graph_failures;
+    return 0;
+}
+
+// ---- opt-in "fast" precision ------------------------------------------------------------------------------------------------
+extern "C" int mvlm_cnn_load_fast(mvlm_ctx* ctx, const uint16_t* blob_host, size_t n_u16, const int64_t* slot_offsets, int n_slots) {
+    MVLM_ENTER(ctx);
+    CnnState& st = ctx->cnn;
+    MVLM_REQUIRE(ctx, st.loaded, "cnn_load_fast: mvlm_cnn_load comes first");
+    MVLM_REQUIRE(ctx, blob_host && slot_offsets && n_u16 > 0 && size_t(n_slots) * MVLM_CONV_DESC_INTS == st.desc.size(),
+                 "cnn_load_fast: bad arguments");
+    for (int s = 0; s < n_slots; ++s) {
+        if (slot_offsets[s] < 0) continue;
+        const int32_t* r = &st.desc[size_t(s) * MVLM_CONV_DESC_INTS];
+        MVLM_REQUIRE(ctx, r[0] && r[3] == 3 && r[4] % 16 == 0 && r[5] % 64 == 0, "cnn_load_fast: slot is not a fast-eligible 3x3 layer");
+        const size_t need = size_t(r[4] / 16) * 9 * 2 * 3 * size_t(r[5]) * 8;
+        MVLM_REQUIRE(ctx, slot_offsets[s] % 8 == 0 && size_t(slot_offsets[s]) + need <= n_u16, "cnn_load_fast: offset out of range");
+    }
+    for (auto& g : st.graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    st.graphs.clear();
+    st.fast = 0;
+    if (st.fast_blob) {
+        MVLM_CHECK_HIP(ctx, hipFree(st.fast_blob));
+        st.fast_blob = nullptr;
+    }
+    MVLM_CHECK_HIP(ctx, hipMalloc(&st.fast_blob, n_u16 * sizeof(uint16_t)));
+    MVLM_CHECK_HIP(ctx, hipMemcpy(st.fast_blob, blob_host, n_u16 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    st.fast_off.assign(slot_offsets, slot_offsets + n_slots);
+    return 0;
+}
+
+extern "C" int mvlm_cnn_set_precision(mvlm_ctx* ctx, int fast) {
+    MVLM_ENTER(ctx);
+    CnnState& st = ctx->cnn;
+    MVLM_REQUIRE(ctx, fast == 0 || fast == 1, "cnn_set_precision: 0 (exact fp32) or 1 (bf16x3 split on the eligible layers)");
+    MVLM_REQUIRE(ctx, !fast || st.fast_blob, "cnn_set_precision: mvlm_cnn_load_fast has not been called");
+    if (fast != st.fast) {  // captured graphs encode the kernels
+        for (auto& g : st.graphs)
+            if (g.exec) hipGraphExecDestroy(g.exec);
+        st.graphs.clear();
+    }
+    st.fast = fast;
     return 0;
 }
 

@@ -141,6 +141,10 @@ struct CnnState {
     size_t sync_cursor = 0;
     int graph_mode = 1;            // 0: always eager, 1: replay captured graphs when not profiling
     int concurrency = 0;           // 0: one stream (default), 1: lower hourglass pyramid on a side stream (small batches)
+    // opt-in "fast" precision (conv_fast.hip): bf16x3-split weights of the eligible 3x3 layers, per conv slot
+    unsigned short* fast_blob = nullptr;
+    std::vector<long long> fast_off;   // u16 element offset per slot, -1 = the layer stays on the exact kernel
+    int fast = 0;                      // 1: eligible layers run on the bf16x3 kernel
     std::vector<CnnGraphEntry> graphs;
     long graph_replays = 0, graph_captures = 0, eager_runs = 0, graph_failures = 0;
 };
@@ -195,6 +199,11 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
 bool mvlm_conv_can_pool(const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
 int mvlm_conv_amax_parts(int H, int W);  // partials per (image, channel) the argmax epilogue writes
 const char* mvlm_conv_variant_name_impl(int v);
+
+// conv_fast.hip (opt-in reduced-cost arithmetic)
+bool mvlm_conv_fast_ok(const ConvArgs& a);
+int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev);
+constexpr int MVLM_CONV_VARIANT_FAST = 62;  // id reported for launches of the bf16x3 kernel
 
 // small kernels (misc.hip)
 int mvlm_launch_pack_input(mvlm_ctx* ctx, const float* images, int n, const int* sel4, int c, float* out);

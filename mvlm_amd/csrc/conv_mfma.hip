@@ -101,6 +101,7 @@ int pick_variant(const ConvArgs& a, bool rules_only = false) {
 }  // namespace
 
 const char* mvlm_conv_variant_name_impl(int v) {
+    if (v == MVLM_CONV_VARIANT_FAST) return "conv3x3_bf16x3_t8x32";
     switch (v) {
 #define X(id, name, ...) \
     case id:             \

@@ -27,14 +27,27 @@ namespace {
 
 constexpr int TILES = RM_TILES * RM_TILES;  // 256 per view
 
+// Workgroup -> (view, chunk of that view's work) so that every view is worked on by ONE XCD: consecutive block ids
+// go round-robin over the 8 XCDs, each with its own L2; a view's transformed vertices (0.8 MB), key plane (0.5 MB) and
+// bins then live in one L2 instead of being fetched by all eight (speed heuristic only: any placement is correct).
+// The grid holds ceil(n_views / 8) * 8 * chunks_per_view workgroups; surplus ones return at once.
+__device__ inline bool view_chunk(int chunks_per_view, int n_views, int* view, int* chunk) {
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    *view = (j / chunks_per_view) * 8 + xcd;
+    *chunk = j % chunks_per_view;
+    return *view < n_views;
+}
+inline unsigned view_chunk_grid(int chunks_per_view, int n_views) { return unsigned((n_views + 7) / 8 * 8) * unsigned(chunks_per_view); }
+
 __global__ void transform_kernel(const float* __restrict__ verts, int n_verts, const double* __restrict__ rot,
                                  int n_views, rm_vert* __restrict__ tv) {
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= long(n_views) * n_verts) return;
-    const int view = int(i / n_verts), v = int(i - long(view) * n_verts);
+    int view, chunk;
+    if (!view_chunk((n_verts + 255) / 256, n_views, &view, &chunk)) return;
+    const int v = chunk * 256 + int(threadIdx.x);
+    if (v >= n_verts) return;
     double m[9];
     for (int k = 0; k < 9; ++k) m[k] = rot[view * 9 + k];
-    tv[i] = rm_transform(m, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
+    tv[size_t(view) * n_verts + v] = rm_transform(m, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
 }
 
 __device__ inline rm_tri load_tri(const rm_vert* tvv, const int32_t* tris, int t) {
@@ -48,9 +61,10 @@ constexpr int SMALL_PIXELS = 16;  // triangles covering at most this many pixel 
 __global__ void classify_kernel(const rm_vert* __restrict__ tv, const int32_t* __restrict__ tris, int n_verts,
                                 int n_tris, int n_views, unsigned long long* __restrict__ keys,
                                 int* __restrict__ counts, int* __restrict__ n_big, int* __restrict__ big_list) {
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= long(n_views) * n_tris) return;
-    const int view = int(i / n_tris), t = int(i - long(view) * n_tris);
+    int view, chunk;
+    if (!view_chunk((n_tris + 255) / 256, n_views, &view, &chunk)) return;
+    const int t = chunk * 256 + int(threadIdx.x);
+    if (t >= n_tris) return;
     const rm_tri tr = load_tri(tv + size_t(view) * n_verts, tris, t);
     if (!tr.valid) return;
     const int w = tr.ix1 - tr.ix0 + 1, h = tr.iy1 - tr.iy0 + 1;
@@ -78,9 +92,9 @@ __global__ void bin_fill_kernel(const rm_vert* __restrict__ tv, const int32_t* _
                                 const int* __restrict__ big_list, const int* __restrict__ offsets,
                                 int* __restrict__ cursors, int* __restrict__ bins, int cap,
                                 int* __restrict__ overflow) {
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= long(n_views) * n_tris) return;
-    const int view = int(i / n_tris), k = int(i - long(view) * n_tris);
+    int view, chunk;
+    if (!view_chunk((n_tris + 255) / 256, n_views, &view, &chunk)) return;
+    const int k = chunk * 256 + int(threadIdx.x);
     if (k >= n_big[view]) return;
     const int t = big_list[size_t(view) * n_tris + k];
     const rm_tri tr = load_tri(tv + size_t(view) * n_verts, tris, t);
@@ -117,16 +131,18 @@ __global__ __launch_bounds__(256) void tile_kernel(const rm_vert* __restrict__ t
                                                    int tex_w, int tex_h, int n_verts, const int* __restrict__ counts,
                                                    const int* __restrict__ offsets, const int* __restrict__ bins,
                                                    int cap, const unsigned long long* __restrict__ keys,
-                                                   int shading, float* __restrict__ out) {
+                                                   int shading, int n_views, float* __restrict__ out) {
     __shared__ rm_tri s_tri[256];
     __shared__ int s_id[256];
-    const int view = blockIdx.x / TILES, tile = blockIdx.x % TILES;
+    int view, tile;
+    if (!view_chunk(TILES, n_views, &view, &tile)) return;
+    const int vt = view * TILES + tile;
     const int tid = threadIdx.x;
     const int i = (tile % RM_TILES) * RM_TILE + (tid & (RM_TILE - 1));
     const int j = (tile / RM_TILES) * RM_TILE + (tid >> 4);
     const rm_vert* tvv = tv + size_t(view) * n_verts;
-    const int n = min(counts[blockIdx.x], cap - offsets[blockIdx.x]);
-    const int* list = bins + size_t(view) * cap + offsets[blockIdx.x];
+    const int n = min(counts[vt], cap - offsets[vt]);
+    const int* list = bins + size_t(view) * cap + offsets[vt];
 
     uint64_t best = keys[(size_t(view) * RM_SIZE + j) * RM_SIZE + i];  // what the small triangles left
     for (int base = 0; base < n; base += 256) {
@@ -207,7 +223,6 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
                                        ctx->stream));
     MVLM_CHECK_HIP(ctx, hipMemsetAsync(ctr, 0, ctr_ints * sizeof(int), ctx->stream));
     MVLM_CHECK_HIP(ctx, hipMemsetAsync(keys, 0xFF, key_bytes, ctx->stream));  // RM_KEY_EMPTY everywhere
-    const long nv = long(n_views) * V, nt = long(n_views) * T;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->render_profiling) {  // HIP events on the launch stream around the five kernels of this call
         if (ctx->render_event_cursor + 2 > ctx->render_events.size()) ctx->render_events.resize(ctx->render_event_cursor + 2, nullptr);
@@ -220,15 +235,16 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
         ctx->render_event_cursor += 2;
         MVLM_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
-    hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, mesh->verts, V,
-                       rot, n_views, tv);
-    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris, V,
-                       T, n_views, keys, counts, n_big, big_list);
+    hipLaunchKernelGGL(transform_kernel, dim3(view_chunk_grid((V + 255) / 256, n_views)), dim3(256), 0, ctx->stream,
+                       mesh->verts, V, rot, n_views, tv);
+    hipLaunchKernelGGL(classify_kernel, dim3(view_chunk_grid((T + 255) / 256, n_views)), dim3(256), 0, ctx->stream, tv,
+                       mesh->tris, V, T, n_views, keys, counts, n_big, big_list);
     hipLaunchKernelGGL(scan_kernel, dim3(n_views), dim3(TILES), 0, ctx->stream, counts, offsets, cap, overflow);
-    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, tv, mesh->tris,
-                       V, T, n_views, n_big, big_list, offsets, cursors, bins, cap, overflow);
-    hipLaunchKernelGGL(tile_kernel, dim3(n_views * TILES), dim3(256), 0, ctx->stream, tv, mesh->tris, mesh->uvs,
-                       mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys, ctx->render_shading, out_dev);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(view_chunk_grid((T + 255) / 256, n_views)), dim3(256), 0, ctx->stream, tv,
+                       mesh->tris, V, T, n_views, n_big, big_list, offsets, cursors, bins, cap, overflow);
+    hipLaunchKernelGGL(tile_kernel, dim3(view_chunk_grid(TILES, n_views)), dim3(256), 0, ctx->stream, tv, mesh->tris,
+                       mesh->uvs, mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys,
+                       ctx->render_shading, n_views, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     if (e1) {
         MVLM_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));

@@ -6,7 +6,7 @@ from .general_pipeline import Pipeline
 
 __all__ = ["BU3DFEPipeline", "DTU3DPipeline"]
 
-_PREDICTOR_KEYS = ("weights", "image_mode", "selection_method", "batch_size", "device_batch", "model_dir")
+_PREDICTOR_KEYS = ("weights", "image_mode", "selection_method", "batch_size", "device_batch", "model_dir", "precision")
 
 
 def _split(kwargs):

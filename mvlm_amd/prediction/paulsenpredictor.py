@@ -51,7 +51,8 @@ class HipPaulsenModel(Predictor2D):
     ``"synthetic:<seed>"`` -> seeded random weights (benchmarks, tests)."""
 
     def __init__(self, model_type: str, image_mode: str, n_gpus=1, batch_size=2, selection_method="simple",
-                 weights=None, device: int = 0, device_batch: int | None = None, model_dir=None, verbose: bool = True):
+                 weights=None, device: int = 0, device_batch: int | None = None, model_dir=None, verbose: bool = True,
+                 precision: str = "exact"):
         super().__init__()
         if image_mode not in arch.IMAGE_CHANNELS:
             raise ValueError("Image channels should be: geometry, RGB, depth, RGB+depth or geometry+depth")
@@ -76,6 +77,25 @@ class HipPaulsenModel(Predictor2D):
         self.ctx.check(self.ctx.lib.mvlm_cnn_load(
             self.ctx.handle, _lib.as_ptr(blob, C.c_float), blob.size, _lib.as_ptr(desc, C.c_int32), desc.shape[0],
             self.get_lm_count(), self.in_channels))
+        self._state_dict, self._desc = state_dict, desc
+        self._fast_loaded = False
+        self.precision = "exact"
+        self.set_precision(precision)
+
+    def set_precision(self, precision: str):
+        """"exact" (default): every convolution in exact fp32 on the matrix cores - the path all parity claims are
+        about.  "fast" (opt-in): the big 3x3 layers multiply bf16x3-split operands (mvlm_amd/csrc/conv_fast.hip),
+        fp32-accurate but not bit-identical: argmax near-ties may flip, see bench.py's ``fast_mode`` figures."""
+        if precision not in ("exact", "fast"):
+            raise ValueError("precision must be 'exact' or 'fast'")
+        if precision == "fast" and not self._fast_loaded:
+            blob16, offsets = W.pack_fast_for_device(self._state_dict, self.get_lm_count(), self.in_channels, self._desc)
+            self.ctx.check(self.ctx.lib.mvlm_cnn_load_fast(
+                self.ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
+                offsets.ctypes.data_as(C.POINTER(C.c_int64)), offsets.shape[0]))
+            self._fast_loaded = True
+        self.ctx.check(self.ctx.lib.mvlm_cnn_set_precision(self.ctx.handle, 1 if precision == "fast" else 0))
+        self.precision = precision
 
     @abc.abstractmethod
     def get_lm_count(self) -> int:

@@ -180,3 +180,37 @@ def pack_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: in
             row[10], row[11] = push(a), push(b)
     blob = np.concatenate(parts) if parts else np.zeros(0, np.float32)
     return blob, desc
+
+
+def pack_fast_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: int, desc: np.ndarray):
+    """Weights of the layers the opt-in "fast" precision serves (mvlm_amd/csrc/conv_fast.hip): every present 3x3 conv
+    whose padded input channels are a multiple of 16 and padded output channels a multiple of 64, split into three
+    bf16 terms and laid out by the library's own packer (mvlm_pack_fast_weights).  ``desc`` is the descriptor table of
+    ``pack_for_device`` (it fixes the paddings).  Returns (blob uint16[total], offsets int64[N_CONV_SLOTS], -1 = the
+    layer stays on the exact kernel)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    slots = arch.conv_slots(n_landmarks, in_channels)
+    offsets = np.full(len(slots), -1, dtype=np.int64)
+    parts, cursor = [], 0
+    for s in slots:
+        row = desc[s.index]
+        cin_pad, cout_pad = int(row[4]), int(row[5])
+        if not s.present or s.ksize != 3 or cin_pad % 16 != 0 or cout_pad % 64 != 0:
+            continue
+        w = np.ascontiguousarray(sd[f"{s.name}.weight"], dtype=np.float32)
+        n = int(lib.mvlm_pack_fast_weights(_lib.as_ptr(w, C.c_float), s.cout, s.cin, cout_pad, cin_pad, None))
+        if n == 0:
+            raise ValueError(f"mvlm_pack_fast_weights refused layer {s.name}")
+        buf = np.empty(n, dtype=np.uint16)
+        if int(lib.mvlm_pack_fast_weights(_lib.as_ptr(w, C.c_float), s.cout, s.cin, cout_pad, cin_pad,
+                                          buf.ctypes.data_as(C.POINTER(C.c_uint16)))) != n:
+            raise ValueError(f"mvlm_pack_fast_weights failed on layer {s.name}")
+        offsets[s.index] = cursor
+        parts.append(buf)
+        cursor += n
+    blob = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
+    return blob, offsets

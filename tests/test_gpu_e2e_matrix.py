@@ -399,3 +399,68 @@ def test_split_k_variants_match_torch(variant, size):
                    + torch.from_numpy(pre[1]).double()[None, :, None, None])
     want = (torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None, 1, 1) + torch.from_numpy(res).double()).numpy()
     assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+
+
+# ---- opt-in "fast" precision (bf16x3 split on the bf16 matrix cores) -----------------------------------------------------
+@pytest.mark.parametrize("cin,cout,size,batch,opts", [
+    (256, 128, 64, 2, dict(pre=True, res=True)),       # a residual block's conv1
+    (256, 256, 32, 1, dict(bias=True, post=True)),     # conv5 / conv9 shape, two 128-channel tiles
+    (128, 64, 32, 3, dict(pre=True, res=True)),        # 64-channel tile
+    (64, 64, 64, 1, dict(pre=True)),
+    (32, 64, 32, 2, dict(bias=True)),                  # two 16-channel chunks
+    (48, 192, 32, 1, dict(pre=True, bias=True)),       # 192 = 3 x 64 tiles, 3 chunks
+])
+def test_fast_conv_matches_torch(cin, cout, size, batch, opts):
+    """mvlm_conv2d_fast (bf16x3-split operands, 6 cross products, fp32 accumulation) against torch float64: the error
+    budget is that of fp32 itself (dropped terms <= 2^-23 per product), nothing like a bf16 convolution's 1e-2."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    rs = np.random.RandomState(cin + cout + size)
+    x = rs.standard_normal((batch, cin, size, size)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32) if opts.get("bias") else None
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32)) if opts.get("pre") else None
+    post = (rs.uniform(0.5, 1.5, cout).astype(np.float32), (rs.standard_normal(cout) * 0.3).astype(np.float32)) if opts.get("post") else None
+    res = rs.standard_normal((batch, cout, size, size)).astype(np.float32) if opts.get("res") else None
+    xd = dev(x)
+    rd = dev(res) if res is not None else None
+    yd = torch.empty((batch, cout, size, size), dtype=torch.float32, device="cuda")
+    p = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+    ctx.check(ctx.lib.mvlm_conv2d_fast(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, p(bias),
+                                       p(pre[0]) if pre else None, p(pre[1]) if pre else None,
+                                       p(post[0]) if post else None, p(post[1]) if post else None,
+                                       C.c_void_p(rd.data_ptr()) if rd is not None else None, C.c_void_p(yd.data_ptr())))
+    t = torch.from_numpy(x).double()
+    if pre:
+        t = torch.relu(t * torch.from_numpy(pre[0]).double()[None, :, None, None] + torch.from_numpy(pre[1]).double()[None, :, None, None])
+    y = torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None if bias is None else torch.from_numpy(bias).double(), 1, 1)
+    if post:
+        y = torch.relu(y * torch.from_numpy(post[0]).double()[None, :, None, None] + torch.from_numpy(post[1]).double()[None, :, None, None])
+    if res is not None:
+        y = y + torch.from_numpy(res).double()
+    want = y.numpy()
+    err = np.abs(yd.cpu().numpy() - want).max()
+    assert err < 1e-5 * max(1.0, np.abs(want).max()), err
+
+
+def test_fast_precision_network_close_to_exact():
+    """precision="fast" on the whole network: heatmaps within 1e-4 of the value range of the exact path's, argmax pixels
+    equal except near-ties; switching back restores the exact path bit for bit."""
+    from conftest import seeded_images
+    from mvlm_amd.prediction import BU3DFEPredictor
+
+    imgs = dev(seeded_images(41, 4))
+    pred = BU3DFEPredictor(image_mode="RGB+depth", weights="synthetic:3", verbose=False)
+    exact_heat = pred.heatmaps_device(imgs).clone()
+    exact_max = pred.predict_device(imgs).clone()
+    pred.set_precision("fast")
+    fast_heat = pred.heatmaps_device(imgs)
+    fast_max = pred.predict_device(imgs)
+    scale = exact_heat.abs().max().item()
+    dev_heat = (fast_heat - exact_heat).abs().max().item()
+    assert 0 < dev_heat < 1e-4 * scale, (dev_heat, scale)          # different arithmetic, fp32-class accuracy
+    flips = (~torch.all(fast_max[:, :, :2] == exact_max[:, :, :2], dim=2)).sum().item()
+    assert flips <= 0.03 * 84 * 4, flips
+    pred.set_precision("exact")
+    assert torch.equal(pred.predict_device(imgs), exact_max)
