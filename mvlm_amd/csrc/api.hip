@@ -281,12 +281,25 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
     const int saved = ctx->conv_force_variant;
     ctx->conv_force_variant = variant >= 0 ? variant : (variant == -2 ? -2 : -1);
     int used = -1;
-    int rc = mvlm_launch_conv(ctx, a, &used);  // warm-up (also sets the launch attributes)
+    unsigned short* wq = nullptr;
+    if (variant == MVLM_CONV_VARIANT_FAST) {  // the opt-in bf16x3 kernel on zero weights (cin_pad must be a multiple of 16)
+        a.cin_pad = (cin + 15) / 16 * 16;
+        a.cout_pad = (cout + 63) / 64 * 64;
+        const size_t n16 = size_t(a.cin_pad / 16) * 9 * 2 * 3 * a.cout_pad * 8;
+        wq = static_cast<unsigned short*>(ctx->get_scratch("conv_bench.wq", n16 * 2));
+        if (!wq || !mvlm_conv_fast_ok(a)) {
+            ctx->conv_force_variant = saved;
+            return ctx->fail("conv_bench: shape not eligible for the fast kernel");
+        }
+        (void)hipMemsetAsync(wq, 0, n16 * 2, ctx->stream);
+    }
+    auto launch = [&](int* v) { return wq ? mvlm_launch_conv_fast(ctx, a, wq) : mvlm_launch_conv(ctx, a, v); };
+    int rc = launch(&used);  // warm-up (also sets the launch attributes)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = ctx->fail("conv_bench: hipEventCreate failed");
     if (!rc) {
         hipEventRecord(e0, ctx->stream);
-        for (int i = 0; i < iters && !rc; ++i) rc = mvlm_launch_conv(ctx, a, nullptr);
+        for (int i = 0; i < iters && !rc; ++i) rc = launch(nullptr);
         hipEventRecord(e1, ctx->stream);
         if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = ctx->fail("conv_bench: kernel failed");
         float ms = 0.f;

@@ -9,14 +9,14 @@
 // argmax near-tie can flip (bench.py reports the measured flip rate; the reference's own precedent is
 // torch.set_float32_matmul_precision("medium"), paulsenpredictor.py:175-176, which is much coarser).
 //
-// Kernel: implicit GEMM like conv_mfma_kernel (same tile geometry 8 rows x 32 pixels, same accumulator layout, so the
-// same kind of epilogue), one 512-thread workgroup per CU:
-//   * 8 waves = 2 (output-channel halves) x 4 (pairs of pixel rows); a wave owns MT x 2 MFMA tiles (MT = COUT_T / 64)
+// Kernel: implicit GEMM like conv_mfma_kernel (32-pixel row tiles, same accumulator layout, so the same kind of
+// epilogue), one 512-thread workgroup per CU; tiles 128 channels x 8 rows or 64 channels x 16 rows:
+//   * 8 waves = 2 (output-channel halves) x 4 (groups of TRI / 4 pixel rows); a wave owns MT x NT = 4 MFMA tiles
 //   * K runs in units of (16 input channels) x (one row of 3 taps).  LDS per stage:
-//       X  [k-half 2][split 3][10 x 34 haloed pixels][8 channels] bf16     32 640 B   (restaged once per 3 units)
-//       W  [tap 3][k-half 2][split 3][COUT_T][8 channels] bf16             288 * COUT_T B
-//     both double-buffered (139 KB at COUT_T = 128): while unit u multiplies, the global loads of unit u + 1 are in
-//     flight; they are converted / split and written to the other stage after the MFMAs; one barrier per unit.
+//       X  [k-half 2][split 3][(TRI + 2) x 34 haloed pixels][8 channels] bf16   32 640 / 58 752 B  (restaged once per 3 units)
+//       W  [tap 3][k-half 2][split 3][COUT_T][8 channels] bf16                  288 * COUT_T B
+//     both double-buffered (139 / 154 KB): while unit u multiplies, the global loads of unit u + 1 are in flight and
+//     their BatchNorm / split / LDS writes are issued between the MFMAs of unit u; one barrier per unit.
 //     A lane's MFMA fragment (8 consecutive channels of one pixel / one output channel) is one ds_read_b128, and
 //     consecutive lanes read consecutive 16-byte slots: conflict-free.
 //   * the consumer-side BatchNorm + ReLU is applied in fp32 before the split, zero padding after it.
@@ -26,6 +26,7 @@
 // height of 8, plain NCHW output with optional bias / post-BN+ReLU / raw copy / one residual.  Everything else (and
 // every layer in the default "exact" precision) runs on conv_mfma_kernel.
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -35,20 +36,27 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 namespace {
 
-constexpr int FT_TW = 32, FT_TRI = 8, FT_PW = FT_TW + 2, FT_PH = FT_TRI + 2, FT_NPIX = FT_PW * FT_PH;  // 340 haloed pixels
-constexpr int FT_X_BYTES = 2 * 3 * FT_NPIX * 16;                                                      // 32 640
+constexpr int FT_TW = 32, FT_PW = FT_TW + 2;
 constexpr int FT_THREADS = 512;
 
-__device__ __forceinline__ unsigned short bf16_bits(float x) {
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ unsigned bf16_bits(float x) {
     const __bf16 h = static_cast<__bf16>(x);  // round to nearest even (v_cvt_pk_bf16_f32)
     unsigned short b;
     __builtin_memcpy(&b, &h, 2);
     return b;
 }
-__device__ __forceinline__ float bf16_value(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
+__device__ __forceinline__ float bf16_value(unsigned b) { return __uint_as_float(b << 16); }
 
 // x -> (h, m, l) bf16 bit patterns with h + m + l == x up to 2^-24 |x|
-__device__ __forceinline__ void split3(float x, unsigned short* h, unsigned short* m, unsigned short* l) {
+__device__ __forceinline__ void split3(float x, unsigned* h, unsigned* m, unsigned* l) {
     *h = bf16_bits(x);
     const float r1 = x - bf16_value(*h);
     *m = bf16_bits(r1);
@@ -56,18 +64,32 @@ __device__ __forceinline__ void split3(float x, unsigned short* h, unsigned shor
     *l = bf16_bits(r2);
 }
 
-template <int COUT_T>
+// COUT_T output channels x (TRI rows x 32 pixels); 8 waves = 2 channel halves x 4 groups of TRI / 4 rows
+template <int COUT_T, int TRI>
+struct FastCfg {
+    static constexpr int MT = COUT_T / 64;               // 32-row MFMA tiles per wave (channels)
+    static constexpr int NT = TRI / 4;                    // 32-pixel row segments per wave
+    static constexpr int PH = TRI + 2, NPIX = FT_PW * PH;  // haloed tile
+    static constexpr int X_BYTES = 2 * 3 * NPIX * 16;      // [k-half][split][pixel][8 ch]
+    static constexpr int W_BYTES = 3 * 2 * 3 * COUT_T * 16;  // one tap row: [tap][k-half][split][cout][8 ch]
+    static constexpr int W_ITEMS = W_BYTES / 16, W_ITERS = (W_ITEMS + FT_THREADS - 1) / FT_THREADS;
+    static constexpr int X_ITEMS = 2 * NPIX, X_ITERS = (X_ITEMS + FT_THREADS - 1) / FT_THREADS;
+    static constexpr int TAP_MFMAS = 6 * MT * NT;          // per tap and wave
+    static constexpr size_t LDS = size_t(2) * X_BYTES + size_t(2) * W_BYTES + 2 * 256 * sizeof(float);
+    static_assert(LDS <= 160 * 1024, "stages must fit the CU's LDS");
+    static_assert(TAP_MFMAS == 24, "the staging schedule below is written for 24 MFMAs per tap");
+    static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
+};
+
+template <int COUT_T, int TRI>
 __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvArgs a, const unsigned short* __restrict__ wq,
                                                                    const int tiles_x, const int tiles_y, const int cout_tiles) {
-    constexpr int MT = COUT_T / 64;                     // 32-row MFMA tiles per wave
-    constexpr int W_BYTES = 3 * 2 * 3 * COUT_T * 16;    // one tap row
-    constexpr int W_ITEMS = W_BYTES / 16;               // 16-byte items of a W stage
-    constexpr int W_ITERS = (W_ITEMS + FT_THREADS - 1) / FT_THREADS;
-    constexpr int X_ITEMS = 2 * FT_NPIX;                // (k-half, pixel) items of an X stage: 8 channels each
-    constexpr int X_ITERS = (X_ITEMS + FT_THREADS - 1) / FT_THREADS;
+    using C = FastCfg<COUT_T, TRI>;
+    constexpr int MT = C::MT, NT = C::NT, NPIX = C::NPIX, X_BYTES = C::X_BYTES, W_BYTES = C::W_BYTES;
+    constexpr int W_ITEMS = C::W_ITEMS, W_ITERS = C::W_ITERS, X_ITEMS = C::X_ITEMS, X_ITERS = C::X_ITERS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fast[];
     unsigned char* const sX = smem_fast;                        // 2 stages
-    unsigned char* const sW = smem_fast + 2 * FT_X_BYTES;       // 2 stages
+    unsigned char* const sW = smem_fast + 2 * X_BYTES;          // 2 stages
     float* const sbn = reinterpret_cast<float*>(sW + 2 * W_BYTES);  // [2][256]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -81,25 +103,26 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
     }
     const int ct = lid % cout_tiles, pt = lid / cout_tiles;
     const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, b0 = pt / (tiles_x * tiles_y);
-    const int x0 = tx * FT_TW, y0 = ty * FT_TRI, co0 = ct * COUT_T;
+    const int x0 = tx * FT_TW, y0 = ty * TRI, co0 = ct * COUT_T;
     const int H = a.H, W = a.W;
     const unsigned HW = unsigned(H) * unsigned(W);
-    const int n_chunks = a.cin_pad / 16, n_units = 3 * n_chunks;
+    const int n_chunks = a.cin_pad / 16;
+    const bool has_bn = a.pre_scale != nullptr;
 
     // ---- staging plans ------------------------------------------------------------------------------------------
     // X: item e -> (k-half kh, haloed pixel p); eight channels 16 chunk + 8 kh + j of that pixel
     unsigned xoff[X_ITERS];   // element offset of channel (8 kh) of chunk 0 at that pixel, or ~0u outside the image
-    int xdst[X_ITERS];        // byte offset inside an X stage of split 0 (+ FT_NPIX * 16 per split)
+    int xdst[X_ITERS];        // byte offset inside an X stage of split 0 (+ NPIX * 16 per split), < 0: no item
     int xkh[X_ITERS];
 #pragma unroll
     for (int i = 0; i < X_ITERS; ++i) {
         const int e = tid + i * FT_THREADS;
-        const int kh = e / FT_NPIX, p = e - kh * FT_NPIX;
+        const int kh = e / NPIX, p = e - kh * NPIX;
         const int yy = p / FT_PW, xx = p - yy * FT_PW;
         const int y = y0 + yy - 1, x = x0 + xx - 1;
         const bool ok = e < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
         xoff[i] = ok ? (unsigned(b0 * a.in_ctot + a.in_coff + 8 * kh) * HW + unsigned(y * W + x)) : 0xFFFFFFFFu;
-        xdst[i] = e < X_ITEMS ? (kh * 3 * FT_NPIX + p) * 16 : -1;
+        xdst[i] = e < X_ITEMS ? (kh * 3 * NPIX + p) * 16 : -1;
         xkh[i] = kh;
     }
     // W: item f -> segment (tap, kh, split) and output channel c of the tile; linear in the host layout
@@ -112,161 +135,262 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
     }
     const size_t w_block = size_t(18) * a.cout_pad * 8;  // u16 elements of one (chunk, tap row) block
 
-    float xv[X_ITERS][8];
-    u32x4 wv[W_ITERS];
+    float xv[X_ITERS][8];      // the next chunk's activations, in flight / waiting for their split
+    unsigned xq[3][4];         // one item's eight channels as bf16 pairs, per split
+    u32x4 wv[W_ITERS];         // the next tap row's weights
 
-    auto load_unit = [&](int u) __attribute__((always_inline)) {
-        const int chunk = u / 3, row = u - chunk * 3;
-        const unsigned short* const wb = wq + size_t(u) * w_block;
+    // ---- staging micro-operations (each one small enough for the shadow of one or two MFMAs) --------------------------
+    auto load_w = [&](int unit) __attribute__((always_inline)) {
+        const unsigned short* const wb = wq + size_t(unit) * w_block;
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i)
             wv[i] = *reinterpret_cast<const u32x4*>(wb + (wsrc[i] != 0xFFFFFFFFu ? wsrc[i] : 0u));
-        if (row == 0) {
-            const float* const base = a.in + size_t(chunk) * 16 * HW;
+    };
+    auto store_w = [&](auto ic, int unit) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const int f = tid + i * FT_THREADS;
+        if (f < W_ITEMS) *reinterpret_cast<u32x4*>(sW + (unit & 1) * W_BYTES + f * 16) = wv[i];
+    };
+    auto load_x = [&](int chunk) __attribute__((always_inline)) {
+        const float* const base = a.in + size_t(chunk) * 16 * HW;
 #pragma unroll
-            for (int i = 0; i < X_ITERS; ++i)
+        for (int i = 0; i < X_ITERS; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool ok = xoff[i] != 0xFFFFFFFFu && chunk * 16 + 8 * xkh[i] + j < a.cin;
-                    xv[i][j] = base[ok ? xoff[i] + unsigned(j) * HW : 0u];
-                }
+            for (int j = 0; j < 8; ++j) {
+                xv[i][j] = base[xoff[i] != 0xFFFFFFFFu ? xoff[i] + unsigned(j) * HW : 0u];  // cin % 16 == 0: every channel exists
+            }
+    };
+    // BatchNorm + ReLU, zero padding, split: channels 2 jp and 2 jp + 1 of item i -> one u32 per split
+    auto convert_pair = [&](auto ic, auto jc, int chunk) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, jp = decltype(jc)::value;
+        unsigned h[2], m[2], l[2];
+        const int c = chunk * 16 + 8 * xkh[i] + 2 * jp;
+        float2 sc = make_float2(1.f, 1.f), sh = make_float2(0.f, 0.f);
+        if (has_bn) {
+            sc = *reinterpret_cast<const float2*>(sbn + c);
+            sh = *reinterpret_cast<const float2*>(sbn + 256 + c);
+        }
+        const bool inside = xoff[i] != 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = xv[i][2 * jp + k];
+            if (has_bn) v = fmaxf(fmaf(v, k ? sc.y : sc.x, k ? sh.y : sh.x), 0.f);
+            v = inside ? v : 0.f;  // zero padding after the activation
+            split3(v, &h[k], &m[k], &l[k]);
+        }
+        xq[0][jp] = h[0] | (h[1] << 16);
+        xq[1][jp] = m[0] | (m[1] << 16);
+        xq[2][jp] = l[0] | (l[1] << 16);
+    };
+    auto store_x = [&](auto ic, auto sc, int chunk) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, sp = decltype(sc)::value;
+        if (xdst[i] >= 0) {
+            u32x4 r;
+            r.x = xq[sp][0];
+            r.y = xq[sp][1];
+            r.z = xq[sp][2];
+            r.w = xq[sp][3];
+            *reinterpret_cast<u32x4*>(sX + (chunk & 1) * X_BYTES + xdst[i] + sp * NPIX * 16) = r;
         }
     };
-    auto store_unit = [&](int u) __attribute__((always_inline)) {
-        const int chunk = u / 3, row = u - chunk * 3;
-        unsigned char* const wdst = sW + (u & 1) * W_BYTES;
-#pragma unroll
-        for (int i = 0; i < W_ITERS; ++i) {
-            const int f = tid + i * FT_THREADS;
-            if (f < W_ITEMS) *reinterpret_cast<u32x4*>(wdst + f * 16) = wv[i];
-        }
-        if (row == 0) {
-            unsigned char* const xd = sX + (chunk & 1) * FT_X_BYTES;
-#pragma unroll
-            for (int i = 0; i < X_ITERS; ++i) {
-                if (xdst[i] < 0) continue;
-                unsigned short hh[8], mm[8], ll[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = chunk * 16 + 8 * xkh[i] + j;
-                    float v = xv[i][j];
-                    if (a.pre_scale != nullptr) v = fmaxf(fmaf(v, sbn[c], sbn[256 + c]), 0.f);
-                    const bool ok = xoff[i] != 0xFFFFFFFFu && c < a.cin;
-                    v = ok ? v : 0.f;  // zero padding after the activation
-                    split3(v, &hh[j], &mm[j], &ll[j]);
-                }
-                auto pack = [](const unsigned short (&s)[8]) {
-                    u32x4 r;
-                    r.x = unsigned(s[0]) | (unsigned(s[1]) << 16);
-                    r.y = unsigned(s[2]) | (unsigned(s[3]) << 16);
-                    r.z = unsigned(s[4]) | (unsigned(s[5]) << 16);
-                    r.w = unsigned(s[6]) | (unsigned(s[7]) << 16);
-                    return r;
-                };
-                *reinterpret_cast<u32x4*>(xd + xdst[i]) = pack(hh);
-                *reinterpret_cast<u32x4*>(xd + xdst[i] + FT_NPIX * 16) = pack(mm);
-                *reinterpret_cast<u32x4*>(xd + xdst[i] + 2 * FT_NPIX * 16) = pack(ll);
-            }
-        }
+    // all of item i at once (prologue)
+    auto stage_item = [&](auto ic, int chunk) __attribute__((always_inline)) {
+        static_for<0, 4>([&](auto jc) { convert_pair(ic, jc, chunk); });
+        static_for<0, 3>([&](auto sc) { store_x(ic, sc, chunk); });
     };
 
     // ---- accumulators and per-lane LDS offsets ----------------------------------------------------------------------
-    f32x16 acc[MT][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    // B fragment of pixel row n of this wave, tap (dy, dx): haloed pixel ((2 wn + n + dy) * PW + l31 + dx), k-half = half
-    int boff[2];
+    // B fragment of pixel row n of this wave, tap (dy, dx): haloed pixel ((NT wn + n + dy) * PW + l31 + dx), k-half = half
+    int boff[NT];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) boff[n] = (half * 3 * FT_NPIX + (2 * wn + n) * FT_PW + l31) * 16;
+    for (int n = 0; n < NT; ++n) boff[n] = (half * 3 * NPIX + (NT * wn + n) * FT_PW + l31) * 16;
     // A fragment of MFMA tile m: output channel wm * 32 MT + 32 m + l31, k-half = half
     int aoff[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) aoff[m] = (half * 3 * COUT_T + wm * 32 * MT + 32 * m + l31) * 16;
 
-    // ---- prologue ---------------------------------------------------------------------------------------------------
-    if (a.pre_scale != nullptr)
+    // ---- prologue: BatchNorm table, chunk 0's activations, unit 0's weights ----------------------------------------------
+    if (has_bn)
         for (int i = tid; i < a.cin_pad; i += FT_THREADS) {
             sbn[i] = a.pre_scale[i];
             sbn[256 + i] = a.pre_shift[i];
         }
-    load_unit(0);
+    load_w(0);
+    load_x(0);
     __syncthreads();  // BatchNorm table visible
-    store_unit(0);
+    static_for<0, W_ITERS>([&](auto ic) { store_w(ic, 0); });
+    static_for<0, X_ITERS>([&](auto ic) { stage_item(ic, 0); });
     __syncthreads();
 
-    for (int u = 0; u < n_units; ++u) {
-        const bool more = u + 1 < n_units;
-        if (more) load_unit(u + 1);
-        const int chunk = u / 3, row = u - chunk * 3;
-        const unsigned char* const xs = sX + (chunk & 1) * FT_X_BYTES;
+    // One unit = (chunk, tap row ROW): 3 taps x 24 MFMAs per wave.  The staging of what comes next is cut into
+    // micro-operations placed BETWEEN the MFMAs (slot q = 24 tap + index): the matrix pipe holds a wave's vector issue
+    // for 8 of an MFMA's 32 cycles, the rest is where BatchNorm / split / LDS writes of the next stage run.
+    //   every unit : global loads of the next unit's weights at q = 0, their LDS writes at q = 24 + 4 i (tap 1)
+    //   ROW == 0   : global loads of the NEXT chunk's activations at q = 1 (two units of lead)
+    //   ROW == 1   : item 0 of the next chunk: pairs at q = 2, 8, 14, 20, splits stored at q = 44, 50, 56
+    //   ROW == 2   : item 1: pairs at q = 2, 6, 10, 14, stores at q = 18, 20, 22; item 2: pairs at q = 28, 32, 36, 40,
+    //                stores at q = 60, 64, 68
+    auto unit = [&](auto rowc, int chunk) __attribute__((always_inline)) {
+        constexpr int ROW = decltype(rowc)::value;
+        const int u = 3 * chunk + ROW;
+        const bool more_w = u + 1 < 3 * n_chunks, more_x = chunk + 1 < n_chunks;
+        const unsigned char* const xs = sX + (chunk & 1) * X_BYTES;
         const unsigned char* const ws = sW + (u & 1) * W_BYTES;
+        bf16x8 af[MT][3], bf[NT][3];
+        static_for<0, 3>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int poff = (ROW * FT_PW + t) * 16;  // tap (ROW, t): dy = ROW, dx = t in the haloed tile
+#if defined(MVLM_FAST_ABLATE_ONE_TAP)  // timing experiment only: fragments are read for the first tap of a unit only
+            if constexpr (t == 0)
+#endif
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int poff = (row * FT_PW + t) * 16;  // tap (row, t): dy = row, dx = t in the haloed tile
-            bf16x8 af[MT][3], bf[2][3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
+            for (int sp = 0; sp < 3; ++sp) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    af[m][s] = *reinterpret_cast<const bf16x8*>(ws + ((t * 6 + s) * COUT_T) * 16 + aoff[m]);
+                    af[m][sp] = *reinterpret_cast<const bf16x8*>(ws + ((t * 6 + sp) * COUT_T) * 16 + aoff[m]);
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    bf[n][s] = *reinterpret_cast<const bf16x8*>(xs + s * FT_NPIX * 16 + boff[n] + poff);
+                for (int n = 0; n < NT; ++n)
+                    bf[n][sp] = *reinterpret_cast<const bf16x8*>(xs + sp * NPIX * 16 + boff[n] + poff);
             }
             // six cross terms, smallest first: (w, x) = (h,l) (l,h) (m,m) | (h,m) (m,h) | (h,h)
             constexpr int WS[6] = {0, 2, 1, 0, 1, 0}, XS[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][WS[p]], bf[n][XS[p]], acc[m][n], 0, 0, 0);
-        }
-        if (more) store_unit(u + 1);
+            static_for<0, 24>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, q = 24 * t + i;
+                constexpr int p = i / (MT * NT), mn = i % (MT * NT), m = mn / NT, n = mn % NT;
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][WS[p]], bf[n][XS[p]], acc[m][n], 0, 0, 0);
+                // ---- side work of slot q ----
+#if defined(MVLM_FAST_ABLATE_NO_STAGING)  // timing experiment only: wrong results
+                if constexpr (q < 0) {
+#else
+                if constexpr (q >= 0) {
+#endif
+                if constexpr (q == 0) {
+                    if (more_w) load_w(u + 1);
+                }
+                if constexpr (q == 1 && ROW == 0) {
+                    if (more_x) load_x(chunk + 1);
+                }
+                if constexpr (q >= 24 && q < 24 + 4 * W_ITERS && (q - 24) % 4 == 0) {
+                    if (more_w) store_w(std::integral_constant<int, (q - 24) / 4>{}, u + 1);
+                }
+                if constexpr (ROW == 1) {
+                    if constexpr (q == 2 || q == 8 || q == 14 || q == 20) {
+                        if (more_x) convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - 2) / 6>{}, chunk + 1);
+                    }
+                    if constexpr (q == 44 || q == 50 || q == 56) {
+                        if (more_x) store_x(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - 44) / 6>{}, chunk + 1);
+                    }
+                }
+                if constexpr (ROW == 2 && X_ITERS >= 2) {
+                    if constexpr (q == 2 || q == 6 || q == 10 || q == 14) {
+                        if (more_x) convert_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - 2) / 4>{}, chunk + 1);
+                    }
+                    if constexpr (q == 18 || q == 20 || q == 22) {
+                        if (more_x) store_x(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - 18) / 2>{}, chunk + 1);
+                    }
+                }
+                if constexpr (ROW == 2 && X_ITERS >= 3) {
+                    if constexpr (q == 28 || q == 32 || q == 36 || q == 40) {
+                        if (more_x) convert_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - 28) / 4>{}, chunk + 1);
+                    }
+                    if constexpr (q == 60 || q == 64 || q == 68) {
+                        if (more_x) store_x(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - 60) / 4>{}, chunk + 1);
+                    }
+                }
+                }
+            });
+        });
         __syncthreads();
+    };
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        unit(std::integral_constant<int, 0>{}, chunk);
+        unit(std::integral_constant<int, 1>{}, chunk);
+        unit(std::integral_constant<int, 2>{}, chunk);
     }
 
     // ---- epilogue: bias, post-BatchNorm + ReLU, raw copy, residual, store -----------------------------------------------
+    // One MFMA tile row (32 channels x NT row segments) at a time: all its residual values are requested first, then
+    // the stores follow; the layer kinds that carry the time run without per-element feature tests.
+    auto epilogue = [&](auto raw_c, auto res_c, auto par_c) __attribute__((always_inline)) {
+        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value;
+        constexpr int PAR = decltype(par_c)::value;  // 0 none, 1 bias, 2 bias + post-BatchNorm + ReLU, 3 decide at run time
+        static_for<0, MT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const int cob = co0 + wm * 32 * MT + 32 * m + 4 * half;  // + (r & 3) + 8 (r >> 2)
+            unsigned pix[NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+            for (int n = 0; n < NT; ++n) pix[n] = unsigned((y0 + NT * wn + n) * W + x0 + l31);
+            float resv[16][NT];
+            if constexpr (RES) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wm * 32 * MT + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co >= a.cout) continue;
-            const float bias = a.bias ? a.bias[co] : 0.f;
-            const float ps = a.post_scale ? a.post_scale[co] : 1.f, pt = a.post_scale ? a.post_shift[co] : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cob + (r & 3) + 8 * (r >> 2);
+                    const float* const p = a.res1 + (size_t(b0) * a.res1_ctot + a.res1_coff + (co < a.cout ? co : 0)) * HW;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int y = y0 + 2 * wn + n, x = x0 + l31;
-                const unsigned pix = unsigned(y * W + x);
-                float v = acc[m][n][r] + bias;
-                if (a.post_scale) v = fmaxf(fmaf(v, ps, pt), 0.f);
-                if (a.out_raw) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix] = v;
-                if (a.res1) v += a.res1[(size_t(b0) * a.res1_ctot + a.res1_coff + co) * HW + pix];
-                if (a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix] = v;
+                    for (int n = 0; n < NT; ++n) resv[r][n] = p[pix[n]];
+                }
             }
-        }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                if (co >= a.cout) continue;
+                float bias = 0.f, ps = 1.f, pt = 0.f;
+                if (PAR == 1 || PAR == 2 || (PAR == 3 && a.bias)) bias = a.bias[co];
+                const bool post = PAR == 2 || (PAR == 3 && a.post_scale);
+                if (post) {
+                    ps = a.post_scale[co];
+                    pt = a.post_shift[co];
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float v = acc[m][n][r] + bias;
+                    if (post) v = fmaxf(fmaf(v, ps, pt), 0.f);
+                    if (RAW) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix[n]] = v;
+                    if constexpr (RES) v += resv[r][n];
+                    if (!RAW || a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
+                }
+            }
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr;
+    if (has_raw && has_res && !a.bias && !a.post_scale && a.out)
+        epilogue(T_{}, T_{}, std::integral_constant<int, 0>{});   // residual block conv1 / conv2
+    else if (!has_raw && has_res && !a.bias && !a.post_scale)
+        epilogue(F_{}, T_{}, std::integral_constant<int, 0>{});   // residual block conv3
+    else if (!has_raw && !has_res && a.bias && a.post_scale)
+        epilogue(F_{}, F_{}, std::integral_constant<int, 2>{});   // conv5 / conv9
+    else if (has_raw && has_res)
+        epilogue(T_{}, T_{}, std::integral_constant<int, 3>{});
+    else if (has_raw)
+        epilogue(T_{}, F_{}, std::integral_constant<int, 3>{});
+    else if (has_res)
+        epilogue(F_{}, T_{}, std::integral_constant<int, 3>{});
+    else
+        epilogue(F_{}, F_{}, std::integral_constant<int, 3>{});
 }
 
-template <int COUT_T>
+template <int COUT_T, int TRI>
 int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
-    constexpr size_t LDS = size_t(2) * FT_X_BYTES + size_t(2) * (3 * 2 * 3 * COUT_T * 16) + 2 * 256 * sizeof(float);
-    static_assert(LDS <= 160 * 1024, "stages must fit the CU's LDS");
+    using C = FastCfg<COUT_T, TRI>;
     const int bit = COUT_T == 128 ? 62 : 63;
     if (!((ctx->conv_attr_mask >> bit) & 1ull)) {
-        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<COUT_T>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS)));
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<COUT_T, TRI>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS)));
         ctx->conv_attr_mask |= 1ull << bit;
     }
-    const int tiles_x = a.W / FT_TW, tiles_y = a.H / FT_TRI, cout_tiles = a.cout_pad / COUT_T;
+    const int tiles_x = a.W / FT_TW, tiles_y = a.H / TRI, cout_tiles = a.cout_pad / COUT_T;
     const long nblk = long(tiles_x) * tiles_y * a.B * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv_fast: bad grid");
-    hipLaunchKernelGGL((conv_bf16x3_kernel<COUT_T>), dim3((unsigned)nblk), dim3(FT_THREADS), LDS, ctx->cur_stream(), a, wq,
+    hipLaunchKernelGGL((conv_bf16x3_kernel<COUT_T, TRI>), dim3((unsigned)nblk), dim3(FT_THREADS), C::LDS, ctx->cur_stream(), a, wq,
                        tiles_x, tiles_y, cout_tiles);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
@@ -276,7 +400,9 @@ int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
 
 // can the fast kernel serve this launch?
 bool mvlm_conv_fast_ok(const ConvArgs& a) {
-    return a.ksize == 3 && a.cin_pad % 16 == 0 && a.cin_pad <= 256 && a.cout_pad % 64 == 0 && a.W % FT_TW == 0 && a.H % FT_TRI == 0 &&
+    // 128-channel tiles cover 8 rows, 64-channel tiles 16 rows (same matrix work per staged input tile)
+    const int rows = a.cout_pad % 128 == 0 ? 8 : 16;
+    return a.ksize == 3 && a.cin % 16 == 0 && a.cin_pad == a.cin && a.cin <= 256 && a.cout_pad % 64 == 0 && a.W % FT_TW == 0 && a.H % rows == 0 &&
            !a.up_in && !a.up_out && !a.res2 && !a.skip && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
 }
 
@@ -284,7 +410,7 @@ int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short
     MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(a) && wq_dev, "conv_fast: launch not eligible");
     const double px = double(a.B) * a.H * a.W, lim = 4294967295.0;
     MVLM_REQUIRE(ctx, px * a.in_ctot < lim, "conv_fast: input tensor exceeds 32-bit element offsets (lower the batch)");
-    return a.cout_pad % 128 == 0 ? launch_fast<128>(ctx, a, wq_dev) : launch_fast<64>(ctx, a, wq_dev);
+    return a.cout_pad % 128 == 0 ? launch_fast<128, 8>(ctx, a, wq_dev) : launch_fast<64, 16>(ctx, a, wq_dev);
 }
 
 // ---- host: split + lay out the weights of one 3x3 convolution -----------------------------------------------------------
