@@ -359,11 +359,12 @@ def main():
             set_profiling(1)
             step()
             n = cnn_ctx.lib.mvlm_cnn_get_profile(cnn_ctx.handle, slot, var, fl, ms, cap)
+            fast_slots = {}
             for i in range(max(n, 0)):
-                q = fast_prof.setdefault(var[i], [0.0, 0.0, 0])
-                q[0] += fl[i]
-                q[1] += ms[i]
-                q[2] += 1
+                for q in (fast_prof.setdefault(var[i], [0.0, 0.0, 0]), fast_slots.setdefault((slot[i], var[i]), [0.0, 0.0, 0])):
+                    q[0] += fl[i]
+                    q[1] += ms[i]
+                    q[2] += 1
             r_ctx.lib.mvlm_render_get_profile(r_ctx.handle, rv, rverts, rtris, rms, 64)
             set_profiling(0)
         finally:
@@ -373,6 +374,12 @@ def main():
             for k, (f, t_ms, cnt) in sorted(fast_prof.items(), key=lambda kv: -kv[1][1]):
                 log(f"  {cnn_ctx.lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt:3d}  {t_ms:8.3f} ms/step  "
                     f"{f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s (fp32-equivalent)")
+            if os.environ.get("MVLM_BENCH_PER_LAYER"):
+                names = [sl.name for sl in arch.conv_slots(nl, c)]
+                sizes = arch.conv_spatial_sizes()
+                for (sl, v), (f, t_ms, cnt) in sorted(fast_slots.items()):
+                    log(f"    slot {sl:3d} {names[sl]:22s} @{sizes[names[sl]]:3d} {cnn_ctx.lib.mvlm_conv_variant_name(v).decode():22s} "
+                        f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
         fk = fast_prof.get(62)
         fast_mode = {"value": round(n_total / t_fast, 2), "unit": "views/s", "ms_per_step": round(1e3 * t_fast, 3),
                      "arithmetic": "opt-in: 3x3 layers with >= 16 input and >= 64 output channels on bf16x3-split operands "

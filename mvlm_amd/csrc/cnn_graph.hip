@@ -735,8 +735,8 @@ extern "C" int mvlm_cnn_load_fast(mvlm_ctx* ctx, const uint16_t* blob_host, size
     for (int s = 0; s < n_slots; ++s) {
         if (slot_offsets[s] < 0) continue;
         const int32_t* r = &st.desc[size_t(s) * MVLM_CONV_DESC_INTS];
-        MVLM_REQUIRE(ctx, r[0] && r[3] == 3 && r[4] % 16 == 0 && r[5] % 64 == 0, "cnn_load_fast: slot is not a fast-eligible 3x3 layer");
-        const size_t need = size_t(r[4] / 16) * 9 * 2 * 3 * size_t(r[5]) * 8;
+        MVLM_REQUIRE(ctx, r[0] && r[3] == 3 && mvlm_fast_channels_ok(r[1], r[2]), "cnn_load_fast: slot is not a fast-eligible 3x3 layer");
+        const size_t need = size_t(mvlm_fast_cin_pad(r[1]) / 16) * 9 * 2 * 3 * size_t(mvlm_fast_cout_pad(r[2])) * 8;
         MVLM_REQUIRE(ctx, slot_offsets[s] % 8 == 0 && size_t(slot_offsets[s]) + need <= n_u16, "cnn_load_fast: offset out of range");
     }
     for (auto& g : st.graphs)

@@ -201,6 +201,13 @@ int mvlm_conv_amax_parts(int H, int W);  // partials per (image, channel) the ar
 const char* mvlm_conv_variant_name_impl(int v);
 
 // conv_fast.hip (opt-in reduced-cost arithmetic)
+// channel paddings of the opt-in bf16x3 kernel (its split weights are packed separately from the exact ones): 16-channel
+// k-chunks, 64-channel tiles.  Served: 16..256 input channels, output padding waste of at most 1.6x (84 -> 128 yes, 32 -> 64 no).
+inline int mvlm_fast_cin_pad(int cin) { return (cin + 15) / 16 * 16; }
+inline int mvlm_fast_cout_pad(int cout) { return (cout + 63) / 64 * 64; }
+inline bool mvlm_fast_channels_ok(int cin, int cout) {
+    return cin >= 16 && cin <= 256 && cout > 0 && cout * 8 >= mvlm_fast_cout_pad(cout) * 5;
+}
 bool mvlm_conv_fast_ok(const ConvArgs& a);
 int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev);
 constexpr int MVLM_CONV_VARIANT_FAST = 62;  // id reported for launches of the bf16x3 kernel

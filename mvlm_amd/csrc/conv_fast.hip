@@ -81,7 +81,8 @@ struct FastCfg {
     static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
 };
 
-template <int COUT_T, int TRI>
+// GEN: the rarely needed parts (input channels that do not fill the last chunk, a second residual) are compiled in
+template <int COUT_T, int TRI, bool GEN>
 __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvArgs a, const unsigned short* __restrict__ wq,
                                                                    const int tiles_x, const int tiles_y, const int cout_tiles) {
     using C = FastCfg<COUT_T, TRI>;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
     const int H = a.H, W = a.W;
     const unsigned HW = unsigned(H) * unsigned(W);
     const int n_chunks = a.cin_pad / 16;
+    const bool partial_cin = GEN && a.cin != a.cin_pad;
     const bool has_bn = a.pre_scale != nullptr;
 
     // ---- staging plans ------------------------------------------------------------------------------------------
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         for (int i = 0; i < X_ITERS; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                xv[i][j] = base[xoff[i] != 0xFFFFFFFFu ? xoff[i] + unsigned(j) * HW : 0u];  // cin % 16 == 0: every channel exists
+                const bool ok = xoff[i] != 0xFFFFFFFFu && (!partial_cin || chunk * 16 + 8 * xkh[i] + j < a.cin);
+                xv[i][j] = base[ok ? xoff[i] + unsigned(j) * HW : 0u];  // branch-free; what is not there is zeroed in convert_pair
             }
     };
     // BatchNorm + ReLU, zero padding, split: channels 2 jp and 2 jp + 1 of item i -> one u32 per split
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         for (int k = 0; k < 2; ++k) {
             float v = xv[i][2 * jp + k];
             if (has_bn) v = fmaxf(fmaf(v, k ? sc.y : sc.x, k ? sh.y : sh.x), 0.f);
-            v = inside ? v : 0.f;  // zero padding after the activation
+            v = inside && (!partial_cin || c + k < a.cin) ? v : 0.f;  // zero padding after the activation; channels past cin
             split3(v, &h[k], &m[k], &l[k]);
         }
         xq[0][jp] = h[0] | (h[1] << 16);
@@ -218,9 +221,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
 
     // ---- prologue: BatchNorm table, chunk 0's activations, unit 0's weights ----------------------------------------------
     if (has_bn)
-        for (int i = tid; i < a.cin_pad; i += FT_THREADS) {
-            sbn[i] = a.pre_scale[i];
-            sbn[256 + i] = a.pre_shift[i];
+        for (int i = tid; i < a.cin_pad; i += FT_THREADS) {  // padding channels: relu(0 * 0 + 0) = 0
+            sbn[i] = i < a.cin ? a.pre_scale[i] : 0.f;
+            sbn[256 + i] = i < a.cin ? a.pre_shift[i] : 0.f;
         }
     load_w(0);
     load_x(0);
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
                     if (post) v = fmaxf(fmaf(v, ps, pt), 0.f);
                     if (RAW) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix[n]] = v;
                     if constexpr (RES) v += resv[r][n];
+                    if (GEN && PAR == 3 && a.res2) v += a.res2[(size_t(b0) * a.res2_ctot + a.res2_coff + co) * HW + pix[n]];
                     if (!RAW || a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
                 }
             }
@@ -362,11 +366,12 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
     using T_ = std::true_type;
     using F_ = std::false_type;
     const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr;
-    if (has_raw && has_res && !a.bias && !a.post_scale && a.out)
+    const bool plain = !a.bias && !a.post_scale && !a.res2;
+    if (has_raw && has_res && plain && a.out)
         epilogue(T_{}, T_{}, std::integral_constant<int, 0>{});   // residual block conv1 / conv2
-    else if (!has_raw && has_res && !a.bias && !a.post_scale)
+    else if (!has_raw && has_res && plain)
         epilogue(F_{}, T_{}, std::integral_constant<int, 0>{});   // residual block conv3
-    else if (!has_raw && !has_res && a.bias && a.post_scale)
+    else if (!has_raw && !has_res && a.bias && a.post_scale && !a.res2)
         epilogue(F_{}, F_{}, std::integral_constant<int, 2>{});   // conv5 / conv9
     else if (has_raw && has_res)
         epilogue(T_{}, T_{}, std::integral_constant<int, 3>{});
@@ -378,19 +383,19 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         epilogue(F_{}, F_{}, std::integral_constant<int, 3>{});
 }
 
-template <int COUT_T, int TRI>
+template <int COUT_T, int TRI, bool GEN>
 int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
     using C = FastCfg<COUT_T, TRI>;
-    const int bit = COUT_T == 128 ? 62 : 63;
+    const int bit = 60 + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0);
     if (!((ctx->conv_attr_mask >> bit) & 1ull)) {
-        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<COUT_T, TRI>),
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<COUT_T, TRI, GEN>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS)));
         ctx->conv_attr_mask |= 1ull << bit;
     }
     const int tiles_x = a.W / FT_TW, tiles_y = a.H / TRI, cout_tiles = a.cout_pad / COUT_T;
     const long nblk = long(tiles_x) * tiles_y * a.B * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv_fast: bad grid");
-    hipLaunchKernelGGL((conv_bf16x3_kernel<COUT_T, TRI>), dim3((unsigned)nblk), dim3(FT_THREADS), C::LDS, ctx->cur_stream(), a, wq,
+    hipLaunchKernelGGL((conv_bf16x3_kernel<COUT_T, TRI, GEN>), dim3((unsigned)nblk), dim3(FT_THREADS), C::LDS, ctx->cur_stream(), a, wq,
                        tiles_x, tiles_y, cout_tiles);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
@@ -398,19 +403,24 @@ int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
 
 }  // namespace
 
-// can the fast kernel serve this launch?
+// can the fast kernel serve this launch?  (its own paddings: mvlm_fast_cin_pad / mvlm_fast_cout_pad, common.h)
 bool mvlm_conv_fast_ok(const ConvArgs& a) {
+    if (a.ksize != 3 || !mvlm_fast_channels_ok(a.cin, a.cout)) return false;
     // 128-channel tiles cover 8 rows, 64-channel tiles 16 rows (same matrix work per staged input tile)
-    const int rows = a.cout_pad % 128 == 0 ? 8 : 16;
-    return a.ksize == 3 && a.cin % 16 == 0 && a.cin_pad == a.cin && a.cin <= 256 && a.cout_pad % 64 == 0 && a.W % FT_TW == 0 && a.H % rows == 0 &&
-           !a.up_in && !a.up_out && !a.res2 && !a.skip && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
+    const int rows = mvlm_fast_cout_pad(a.cout) % 128 == 0 ? 8 : 16;
+    return a.W % FT_TW == 0 && a.H % rows == 0 && !a.up_in && !a.up_out && !a.skip && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
 }
 
-int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev) {
-    MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(a) && wq_dev, "conv_fast: launch not eligible");
+int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& exact, const unsigned short* wq_dev) {
+    MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(exact) && wq_dev, "conv_fast: launch not eligible");
+    ConvArgs a = exact;  // the split weights carry their own paddings
+    a.cin_pad = mvlm_fast_cin_pad(a.cin);
+    a.cout_pad = mvlm_fast_cout_pad(a.cout);
     const double px = double(a.B) * a.H * a.W, lim = 4294967295.0;
     MVLM_REQUIRE(ctx, px * a.in_ctot < lim, "conv_fast: input tensor exceeds 32-bit element offsets (lower the batch)");
-    return a.cout_pad % 128 == 0 ? launch_fast<128, 8>(ctx, a, wq_dev) : launch_fast<64, 16>(ctx, a, wq_dev);
+    if (a.cin != a.cin_pad || a.res2)
+        return a.cout_pad % 128 == 0 ? launch_fast<128, 8, true>(ctx, a, wq_dev) : launch_fast<64, 16, true>(ctx, a, wq_dev);
+    return a.cout_pad % 128 == 0 ? launch_fast<128, 8, false>(ctx, a, wq_dev) : launch_fast<64, 16, false>(ctx, a, wq_dev);
 }
 
 // ---- host: split + lay out the weights of one 3x3 convolution -----------------------------------------------------------
@@ -458,7 +468,8 @@ extern "C" int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, in
                                 const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev) {
     MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, x_dev && w_host && y_dev, "conv2d_fast: null pointer");
-    const int cin_pad = (cin + 15) / 16 * 16, cout_pad = (cout + 63) / 64 * 64;
+    MVLM_REQUIRE(ctx, mvlm_fast_channels_ok(cin, cout), "conv2d_fast: channel counts outside what the fast kernel serves");
+    const int cin_pad = mvlm_fast_cin_pad(cin), cout_pad = mvlm_fast_cout_pad(cout);
     std::vector<uint16_t> wq(mvlm_pack_fast_weights(w_host, cout, cin, cout_pad, cin_pad, nullptr));
     MVLM_REQUIRE(ctx, !wq.empty() && mvlm_pack_fast_weights(w_host, cout, cin, cout_pad, cin_pad, wq.data()) == wq.size(),
                  "conv2d_fast: weight packing failed");

@@ -184,7 +184,7 @@ def pack_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: in
 
 def pack_fast_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: int, desc: np.ndarray):
     """Weights of the layers the opt-in "fast" precision serves (mvlm_amd/csrc/conv_fast.hip): every present 3x3 conv
-    whose padded input channels are a multiple of 16 and padded output channels a multiple of 64, split into three
+    with 16..256 input channels whose output channels fill at least 5/8 of their 64-channel tiles, split into three
     bf16 terms and laid out by the library's own packer (mvlm_pack_fast_weights).  ``desc`` is the descriptor table of
     ``pack_for_device`` (it fixes the paddings).  Returns (blob uint16[total], offsets int64[N_CONV_SLOTS], -1 = the
     layer stays on the exact kernel)."""
@@ -197,9 +197,9 @@ def pack_fast_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channel
     offsets = np.full(len(slots), -1, dtype=np.int64)
     parts, cursor = [], 0
     for s in slots:
-        row = desc[s.index]
-        cin_pad, cout_pad = int(row[4]), int(row[5])
-        if not s.present or s.ksize != 3 or cin_pad % 16 != 0 or cout_pad % 64 != 0:
+        # the kernel's own paddings and limits (mvlm_fast_cin_pad / mvlm_fast_cout_pad / mvlm_fast_channels_ok, common.h)
+        cin_pad, cout_pad = _round_up(s.cin, 16), _round_up(s.cout, 64)
+        if not s.present or s.ksize != 3 or not 16 <= s.cin <= 256 or s.cout * 8 < cout_pad * 5:
             continue
         w = np.ascontiguousarray(sd[f"{s.name}.weight"], dtype=np.float32)
         n = int(lib.mvlm_pack_fast_weights(_lib.as_ptr(w, C.c_float), s.cout, s.cin, cout_pad, cin_pad, None))

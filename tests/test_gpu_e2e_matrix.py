@@ -409,6 +409,9 @@ def test_split_k_variants_match_torch(variant, size):
     (64, 64, 64, 1, dict(pre=True)),
     (32, 64, 32, 2, dict(bias=True)),                  # two 16-channel chunks
     (48, 192, 32, 1, dict(pre=True, bias=True)),       # 192 = 3 x 64 tiles, 3 chunks
+    (84, 256, 32, 2, dict(bias=True, res=True)),       # conv7: 84 input channels in 6 chunks, the last one partly empty
+    (256, 84, 64, 1, dict(bias=True)),                 # conv6 / conv10: 84 output channels in one 128-channel tile
+    (84, 84, 32, 1, dict(pre=True, bias=True, post=True)),
 ])
 def test_fast_conv_matches_torch(cin, cout, size, batch, opts):
     """mvlm_conv2d_fast (bf16x3-split operands, 6 cross products, fp32 accumulation) against torch float64: the error

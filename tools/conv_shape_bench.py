@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Time single convolution layers through mvlm_conv_bench (zero data: optimistic clocks, good for A/B only).
+usage: conv_shape_bench.py B,cin,cout,size,flags[,variant] ...   (flags: 1 pre-BN, 2 residual+raw, 4 bias, 8 post-BN;
+variant 62 = the opt-in bf16x3 kernel, -2 = rule-based exact, -1 = tuned exact)"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from mvlm_amd import _lib  # noqa: E402
+
+ctx = _lib.get_context(0)
+for spec in sys.argv[1:]:
+    f = [int(v) for v in spec.split(",")]
+    b, cin, cout, size, flags = f[:5]
+    for v in ([f[5]] if len(f) > 5 else [62, -1]):
+        ms, used = C.c_float(), C.c_int()
+        rc = ctx.lib.mvlm_conv_bench(ctx.handle, b, cin, cout, 3, size, flags, v, 6, C.byref(ms), C.byref(used))
+        fl = 2.0 * cin * cout * 9 * size * size * b
+        print(f"B{b} {cin}->{cout} @{size} flags {flags} variant {v:3d}: rc {rc} {ms.value * 1e3:9.1f} us "
+              f"{fl / (ms.value * 1e-3) / 1e12 if rc == 0 and ms.value > 0 else 0:7.1f} TFLOP/s (fp32-equivalent)", flush=True)
