@@ -382,7 +382,7 @@ def main():
                         f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
         fk = fast_prof.get(62)
         fast_mode = {"value": round(n_total / t_fast, 2), "unit": "views/s", "ms_per_step": round(1e3 * t_fast, 3),
-                     "arithmetic": "opt-in: 3x3 layers with >= 16 input and >= 64 output channels on bf16x3-split operands "
+                     "arithmetic": "opt-in: 3x3 layers with 16..256 input and >= 64 output channels on 32-pixel rows on bf16x3-split operands "
                                    "(6 of 9 cross products, v_mfma_f32_32x32x16_bf16, fp32 accumulate); everything else exact fp32",
                      "argmax_planes_differing_from_exact": differ, "argmax_planes": int(max_exact.shape[0] * max_exact.shape[1]),
                      "max_landmark_deviation_vs_exact_model_units": round(float(np.abs(lm_fast - lm_exact).max()), 6),
