@@ -212,7 +212,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = "none"
-    if world > 1:
+    # MVLM_BENCH_FORCE_DIST=1: take the multi-rank path (process group, sharded pipeline, collectives) with whatever
+    # world size there is - under torch.distributed.run --nproc-per-node 1 this rehearses RCCL itself on a one-GPU box
+    sharded = world > 1 or (os.environ.get("MVLM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if sharded:
         import torch.distributed as dist
 
         # the communication libraries may log to fd 1 while they connect (gloo does): stdout is reserved for
@@ -244,25 +247,25 @@ def main():
     if fusion_only:
         from mvlm_amd import pipeline
 
-        pipe = pipeline.Pipeline(n_views=n_total, device=local_rank, shard_views=world > 1, verbose=False)
+        pipe = pipeline.Pipeline(n_views=n_total, device=local_rank, shard_views=sharded, verbose=False)
         nl, c, cfg = spec["landmarks"], 0, None
     else:
         cfg = config.load_config(config.default_config(spec["dataset"], spec["mode"], n_views=n_total))
-        pipe = cfg.build_pipeline(weights="synthetic:0", device=local_rank, shard_views=world > 1, verbose=False,
+        pipe = cfg.build_pipeline(weights="synthetic:0", device=local_rank, shard_views=sharded, verbose=False,
                                   device_batch=args.device_batch)
         nl, c = pipe.get_lm_count(), cfg.in_channels
     pipe.renderer_3d.n_views = n_total
     np.random.seed(0)
     poses = pipe.renderer_3d.generate_3d_transformations() if rank == 0 else None
     poses = parallel.broadcast_array(poses, (n_total, 6), device=local_rank)
-    lo, hi = parallel.shard_range(n_total, rank, world) if world > 1 else (0, n_total)
+    lo, hi = parallel.shard_range(n_total, rank, world) if sharded else (0, n_total)
     if fusion_only:
         pred, pred_state, _ = synthetic_landmark_predictor(mesh, poses, nl, torch.device("cuda", local_rank))
         pred_state["lo"] = lo
         pipe.predictor_2d = pred
 
     def barrier():
-        if world > 1:
+        if sharded:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -338,7 +341,7 @@ def main():
 
     # ---- opt-in "fast" precision (bf16x3 split, mvlm_amd/csrc/conv_fast.hip): a separate figure, never `value` ----------
     fast_mode = None
-    if world == 1 and not fusion_only and not args.no_fast_mode:
+    if not sharded and not fusion_only and not args.no_fast_mode:
         p2 = pipe.predictor_2d
         lm_exact, _ = step()
         images = pipe._buffers["images"]
@@ -388,7 +391,7 @@ def main():
                      "max_landmark_deviation_vs_exact_model_units": round(float(np.abs(lm_fast - lm_exact).max()), 6),
                      "fast_kernel_launches_per_step": fk[2] if fk else 0,
                      "fast_kernel_fp32_equivalent_tflops": round(fk[0] / (fk[1] * 1e-3) / 1e12, 1) if fk else None}
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -441,7 +444,7 @@ def main():
             roof, roof_r = roof_r, None
         log("stage seconds (last step):", {k: round(v, 5) for k, v in pipe.timings.items()})
         ingest = None
-        if world == 1 and not fusion_only and not os.environ.get("MVLM_BENCH_NO_INGEST"):
+        if not sharded and not fusion_only and not os.environ.get("MVLM_BENCH_NO_INGEST"):
             ingest = ingest_figures(pipe, n_total)
         cpu = None
         n_cpu = min(n_total, 96) if args.cpu_views < 0 else min(args.cpu_views, n_total)
@@ -471,7 +474,7 @@ def main():
                        "in_channels": c, "triangles": mesh.n_tris,
                        "live_conv_gflop_per_view": round(flops_view / 1e9, 2),
                        "parallelism": f"views sharded {per_gpu}/GPU x {world} ({args.scaling} scaling; backend {backend}), "
-                                      "1 all-gather of maxima + 1 broadcast of RANSAC draws per mesh" if world > 1
+                                      "1 all-gather of maxima + 1 broadcast of RANSAC draws per mesh" if sharded
                                       else "1 GPU, no collective"},
             "roofline": roof,
             "roofline_rasteriser": roof_r,
@@ -483,7 +486,7 @@ def main():
             "with_ingest": ingest,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

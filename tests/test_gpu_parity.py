@@ -375,13 +375,17 @@ def test_full_size_render_is_deterministic_and_view_consistent():
 # --------------------------------------------------------------------------------------
 # view sharding end to end: two ranks (sharing the one GPU of the test box, gloo) must return
 # exactly what a single process returns
-def _shard_worker(rank, world, port, obj, q):
+def _shard_worker(rank, world, port, obj, q, backend="gloo"):
     import os
 
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":  # = RCCL; the recipe of INTEGRATION.md "Multi-GPU"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from mvlm_amd import pipeline
 
     pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False, shard_views=True)
@@ -418,6 +422,39 @@ def test_sharded_views_equal_single_process(tmp_path):
         assert p.exitcode == 0
     np.testing.assert_array_equal(res[0], want)
     np.testing.assert_array_equal(res[1], want)
+
+
+def test_sharded_path_on_rccl_world_of_one(tmp_path):
+    """The sharded code path with backend "nccl" (= RCCL): the test box has one GPU, so the world is one rank - the
+    collectives (pose broadcast, draw broadcast, all-gather of the maxima) still go through RCCL with the tensors,
+    dtypes and devices the 8-GPU run uses, and the result must equal the unsharded pipeline's."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    obj = write_face_like_obj(tmp_path / "face.obj", grid=40, tex_size=64, seed=2)
+    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False)
+    np.random.seed(4)
+    want = pipe.predict_one_file(obj)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_shard_worker, args=(0, 1, port, obj, q, "nccl"))
+    p.start()
+    try:
+        rank, got = q.get(timeout=240)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert p.exitcode == 0
+    np.testing.assert_array_equal(got, want)
 
 
 def test_cli_writes_landmark_files(tmp_path):
