@@ -93,6 +93,11 @@ struct ConvArgs {
     int sub_y = 0, sub_x = 0;  // up_out == 2 / ksize == 2: output parity = 2x2 window offset in the halo tile
     const float* skip = nullptr;
     int skip_ctot = 0, skip_coff = 0;
+    // split-K tiles only: input channels divided over `kparts` workgroups per output tile (set by the variant id);
+    // kws = partial tiles [tile][part][16][64] f32, kcnt = one arrival counter per tile (zero between launches)
+    int kparts = 1;
+    float* kws = nullptr;
+    unsigned* kcnt = nullptr;
     // fused per-(image, channel) argmax partials (conv11): [B][cout][n_part]
     float* amax_val = nullptr;
     int* amax_idx = nullptr;
@@ -175,6 +180,8 @@ struct mvlm_ctx {
     CnnState cnn;
     // grow-only internal scratch (raster bins, transformed vertices, small staging)
     std::map<std::string, std::pair<void*, size_t>> scratch;
+    float* kparts_ws[2] = {nullptr, nullptr};      // split-K over workgroups: partial tiles, arrival counters
+    unsigned* kparts_cnt[2] = {nullptr, nullptr};  // ([0] main launch stream, [1] the executor's side stream)
     int conv_force_variant = -1;            // >= 0: mvlm_conv_bench times exactly this kernel variant
     unsigned long long conv_attr_mask = 0;  // conv variants whose launch attributes are set on this ctx's device
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
@@ -195,6 +202,9 @@ struct mvlm_ctx {
 };
 
 // conv_mfma.hip
+constexpr long MVLM_KPARTS_MAX_TILES = 2048;  // output tiles of a launch that divides K over workgroups
+constexpr long MVLM_KPARTS_MAX_PARTS = 4096;  // tiles x parts (4 KB of partial sums each)
+int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt);
 int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
 bool mvlm_conv_can_pool(const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
 int mvlm_conv_amax_parts(int H, int W);  // partials per (image, channel) the argmax epilogue writes

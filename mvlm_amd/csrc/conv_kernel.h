@@ -241,6 +241,16 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    // split-K tiles may also split the input channels over `kparts` workgroups (grid = tiles x kparts, the parts of a
+    // tile adjacent): each sums its channel range, the last one to finish adds the partial tiles in part order
+    int kp = 0;
+    if constexpr (C::SPLITK) {
+        if (a.kparts > 1) {
+            kp = lid % a.kparts;
+            lid /= a.kparts;
+        }
+    }
+    const int tile_id = lid;
     const int ct = lid % cout_tiles;
     const int pt = lid / cout_tiles;
     const int tx = pt % tiles_x;
@@ -322,21 +332,27 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     float* sbn = smem + 2 * C::STAGE;
     StageRegs<C> regs;
     constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
-    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true>(a, 0, tid, HWin, sbn, goff, woff_g, regs, smem); });
+    int cb0 = 0, cb1 = a.cin_pad;  // this workgroup's input channels
+    if constexpr (C::SPLITK) {
+        const int span = a.cin_pad / a.kparts;
+        cb0 = kp * span;
+        cb1 = cb0 + span;
+    }
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true>(a, cb0, tid, HWin, sbn, goff, woff_g, regs, smem); });
     if (a.pre_scale != nullptr) {
         for (int i = tid; i < a.cin_pad; i += 256) {
             sbn[i] = a.pre_scale[i];
             sbn[C::BN_MAXC + i] = a.pre_shift[i];
         }
     }
-    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, 0, tid, smem, goff, regs); });
+    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, cb0, tid, smem, goff, regs); });
     __syncthreads();
 
 #if defined(MVLM_CONV_TIMING)
     const long long t_loop = clock64();
 #endif
     int cur = 0;
-    for (int cb = C::CK; cb < a.cin_pad; cb += C::CK) {
+    for (int cb = cb0 + C::CK; cb < cb1; cb += C::CK) {
 #if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
         compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
                                 goff, woff_g, regs, acc, woff16, pixoff16, acc16);
@@ -382,6 +398,26 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         for (int w = 0; w < 3; ++w)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+        if (a.kparts > 1) {
+            // partial tile -> workspace; the workgroup that takes the last ticket of this tile sums all parts in part
+            // order (its own from memory too, so the order does not depend on who arrives last) and runs the epilogue
+            float* const mine = a.kws + (size_t(tile_id) * a.kparts + kp) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[0][0][r];
+            __threadfence();  // release: the partial is visible device-wide before the ticket
+            unsigned ticket = 0;
+            if (lane == 0) ticket = atomicAdd(a.kcnt + tile_id, 1u);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket != unsigned(a.kparts - 1)) return;
+            __threadfence();  // acquire: the other parts' stores
+            if (lane == 0) a.kcnt[tile_id] = 0;  // ready for the next launch on this stream
+            const float* const all = a.kws + size_t(tile_id) * a.kparts * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_nontemporal_load(all + r * 64 + lane);
+            for (int q = 1; q < a.kparts; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += __builtin_nontemporal_load(all + q * 1024 + r * 64 + lane);
+        }
     }
 
     if constexpr (AMAX) {
@@ -846,8 +882,16 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
         MVLM_REQUIRE(ctx, !a.res1 && !a.post_scale && a.up_out != 1, "conv: fused argmax expects a plain conv + bias layer");
         MVLM_REQUIRE(ctx, !a.out && !a.out_raw && !a.pool_out, "conv: a fused-argmax launch does not materialise the heatmap");
     }
-    const long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
+    long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
+    a.kparts = a.kparts > 1 ? a.kparts : 1;
+    if (a.kparts > 1) {
+        MVLM_REQUIRE(ctx, C::SPLITK, "conv: only the split-K tiles divide the input channels over workgroups");
+        MVLM_REQUIRE(ctx, a.cin_pad % (a.kparts * C::CK) == 0, "conv: input channels do not divide into the requested K parts");
+        MVLM_REQUIRE(ctx, nblk <= MVLM_KPARTS_MAX_TILES && nblk * a.kparts <= MVLM_KPARTS_MAX_PARTS, "conv: too many tiles for the K-part workspace");
+        if (mvlm_conv_kparts_workspace(ctx, &a.kws, &a.kcnt)) return 1;
+        nblk *= a.kparts;
+    }
     // dynamic-LDS limit of this variant's kernels: set once per context, i.e. per device (hipFuncSetAttribute
     // applies to the current device's copy of the function; the ctx mutex held by every entry point guards the mask)
     if (!((ctx->conv_attr_mask >> variant_id) & 1ull)) {

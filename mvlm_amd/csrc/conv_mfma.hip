@@ -100,8 +100,30 @@ int pick_variant(const ConvArgs& a, bool rules_only = false) {
 
 }  // namespace
 
+// Variant ids >= 256 are a split-K variant (low byte) whose input channels are divided over 2 / 4 / 8 workgroups per
+// output tile (id = base + 256 log2(parts)); the partial tiles meet in a per-context workspace (one per launch stream).
+int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt) {
+    const int which = (ctx->launch_stream && ctx->launch_stream == ctx->cnn.side_stream) ? 1 : 0;
+    if (!ctx->kparts_ws[0]) {  // both at once, outside any stream capture (a key's first pass is launch by launch)
+        for (int i = 0; i < 2; ++i) {
+            MVLM_CHECK_HIP(ctx, hipMalloc(&ctx->kparts_ws[i], size_t(MVLM_KPARTS_MAX_PARTS) * 1024 * sizeof(float)));
+            MVLM_CHECK_HIP(ctx, hipMalloc(&ctx->kparts_cnt[i], size_t(MVLM_KPARTS_MAX_TILES) * sizeof(unsigned)));
+            MVLM_CHECK_HIP(ctx, hipMemset(ctx->kparts_cnt[i], 0, size_t(MVLM_KPARTS_MAX_TILES) * sizeof(unsigned)));
+        }
+    }
+    *ws = ctx->kparts_ws[which];
+    *cnt = ctx->kparts_cnt[which];
+    return 0;
+}
+
 const char* mvlm_conv_variant_name_impl(int v) {
     if (v == MVLM_CONV_VARIANT_FAST) return "conv3x3_bf16x3_t8x32";
+    if (v >= 256 && v < 1024) {
+        static std::string names[4][256];
+        std::string& n = names[v >> 8][v & 255];
+        if (n.empty()) n = std::string(mvlm_conv_variant_name_impl(v & 255)) + "_k" + std::to_string(1 << (v >> 8));
+        return n.c_str();
+    }
     switch (v) {
 #define X(id, name, ...) \
     case id:             \
@@ -114,7 +136,7 @@ const char* mvlm_conv_variant_name_impl(int v) {
 
 bool mvlm_conv_can_pool(const ConvArgs& a) {
     if (a.up_out || a.amax_val || (a.H & 1) || (a.W & 1)) return false;
-    switch (pick_variant(a)) {
+    switch (pick_variant(a) & 255) {
 #define X(id, name, ...)                                                                                   \
     case id: {                                                                                             \
         using V = __VA_ARGS__;                                                                             \
@@ -151,10 +173,13 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     MVLM_REQUIRE(ctx, !a.pool_out || px / 4 * a.pool_ctot < lim, "conv: pooled output exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, a.out || a.pool_out || a.amax_val, "conv: no output requested");
     if (variant_out) *variant_out = v;
-    switch (v) {
+    MVLM_REQUIRE(ctx, v < 1024, "conv: unknown kernel variant");
+    ConvArgs b = a;
+    b.kparts = 1 << (v >> 8);
+    switch (v & 255) {
 #define X(id, name, ...) \
     case id:             \
-        return mvlm_conv_launch_##id(ctx, a);
+        return mvlm_conv_launch_##id(ctx, b);
         MVLM_CONV_VARIANTS(X)
 #undef X
     }

@@ -371,10 +371,15 @@ def test_fused_argmax_nan_plane_like_numpy():
 
 # ---- every split-K tile variant (32-, 16- and 8-channel chunks) against torch -------------------------------
 @pytest.mark.parametrize("variant,size", [(12, 16), (13, 8), (14, 4), (15, 32), (18, 16), (19, 8), (20, 4), (21, 32),
-                                          (22, 16), (23, 8), (24, 4), (25, 32), (19, 32), (23, 16), (18, 32), (22, 64)])
+                                          (22, 16), (23, 8), (24, 4), (25, 32), (19, 32), (23, 16), (18, 32), (22, 64),
+                                          # + 256 log2(parts): the input channels divided over 2 / 4 / 8 workgroups per tile
+                                          (256 + 13, 8), (512 + 14, 4), (256 + 19, 8), (512 + 23, 8), (768 + 22, 16),
+                                          (768 + 24, 4), (512 + 12, 16), (256 + 21, 32)])
 def test_split_k_variants_match_torch(variant, size):
     """The tuned table may pick any split-K tile for a small level; each one forced onto a residual-block shaped
-    layer (pre-BN, residual add, ragged batch) against torch float64."""
+    layer (pre-BN, residual add, ragged batch) against torch float64.  The variants that divide K over workgroups run
+    four times on changing inputs: the arrival counters must be back at zero after a launch and no part may come from
+    the previous launch's workspace contents."""
     from mvlm_amd import _lib
 
     ctx = _lib.get_context(0)
@@ -390,15 +395,25 @@ def test_split_k_variants_match_torch(variant, size):
     name = ctx.lib.mvlm_conv_variant_name(variant).decode()
     assert name.startswith("conv3x3_sk"), name
     ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, variant))
+    wd = torch.from_numpy(w).double()
+
+    def want(xin):
+        t = torch.relu(torch.from_numpy(xin).double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
+                       + torch.from_numpy(pre[1]).double()[None, :, None, None])
+        return (torch.nn.functional.conv2d(t, wd, None, 1, 1) + torch.from_numpy(res).double()).numpy()
+
     try:
-        ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
-                                      p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())))
+        # fresh inputs every pass: a part read from a stale cache line (the previous launch's partial tile) would show
+        for k in range(4 if variant >= 256 else 1):
+            xk = x if k == 0 else (x * np.float32(1.0 + 0.37 * k) + np.float32(0.11 * k)).astype(np.float32)
+            xd.copy_(torch.from_numpy(xk))
+            yd.fill_(float("nan"))
+            ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
+                                          p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())))
+            expect = want(xk)
+            assert np.abs(yd.cpu().numpy() - expect).max() < 5e-6 * max(1.0, np.abs(expect).max())
     finally:
         ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, -1))
-    t = torch.relu(torch.from_numpy(x).double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
-                   + torch.from_numpy(pre[1]).double()[None, :, None, None])
-    want = (torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None, 1, 1) + torch.from_numpy(res).double()).numpy()
-    assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
 
 
 # ---- opt-in "fast" precision (bf16x3 split on the bf16 matrix cores) -----------------------------------------------------

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Time single convolution layers through mvlm_conv_bench (zero data: optimistic clocks, good for A/B only).
-usage: conv_shape_bench.py B,cin,cout,size,flags[,variant] ...   (flags: 1 pre-BN, 2 residual+raw, 4 bias, 8 post-BN;
-variant 62 = the opt-in bf16x3 kernel, -2 = rule-based exact, -1 = tuned exact)"""
+usage: conv_shape_bench.py B,cin,cout,size,flags[,variant[/variant...]] ...   (flags: 1 pre-BN, 2 residual+raw, 4 bias,
+8 post-BN; variant 62 = the opt-in bf16x3 kernel, -2 = rule-based exact, -1 = tuned exact, + 256 log2(parts) = a split-K
+variant with the input channels divided over workgroups)"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -11,11 +12,11 @@ from mvlm_amd import _lib  # noqa: E402
 
 ctx = _lib.get_context(0)
 for spec in sys.argv[1:]:
-    f = [int(v) for v in spec.split(",")]
-    b, cin, cout, size, flags = f[:5]
-    for v in ([f[5]] if len(f) > 5 else [62, -1]):
+    f = spec.split(",")
+    b, cin, cout, size, flags = (int(v) for v in f[:5])
+    for v in ([int(v) for v in f[5].split("/")] if len(f) > 5 else [62, -1]):
         ms, used = C.c_float(), C.c_int()
-        rc = ctx.lib.mvlm_conv_bench(ctx.handle, b, cin, cout, 3, size, flags, v, 6, C.byref(ms), C.byref(used))
+        rc = ctx.lib.mvlm_conv_bench(ctx.handle, b, cin, cout, 3, size, flags, v, 20, C.byref(ms), C.byref(used))
         fl = 2.0 * cin * cout * 9 * size * size * b
-        print(f"B{b} {cin}->{cout} @{size} flags {flags} variant {v:3d}: rc {rc} {ms.value * 1e3:9.1f} us "
+        print(f"B{b} {cin}->{cout} @{size} flags {flags} variant {v:3d} {ctx.lib.mvlm_conv_variant_name(used.value if v < 0 else v).decode():24s}: rc {rc} {ms.value * 1e3:9.1f} us "
               f"{fl / (ms.value * 1e-3) / 1e12 if rc == 0 and ms.value > 0 else 0:7.1f} TFLOP/s (fp32-equivalent)", flush=True)

@@ -54,6 +54,10 @@ def main():
             if s.name not in users:
                 users.append(s.name)
     names = {v: lib.mvlm_conv_variant_name(v).decode() for v in range(N_VARIANTS)}
+    # split-K tiles with the input channels divided over 2 / 4 workgroups per output tile (id + 256 log2(parts)): they
+    # only pay at the 8x8 / 4x4 levels of small batches (measured: slower from 16x16 up)
+    kpart_ids = [v + 256 * lg for v in range(N_VARIANTS) if names[v].startswith("conv3x3_sk") for lg in (1, 2)]
+    names.update({v: lib.mvlm_conv_variant_name(v).decode() for v in kpart_ids})
     table = []
     for batch in [int(b) for b in args.batches.split(",")]:
         for (k, cin, cout, size, flags), users in sorted(shapes.items()):
@@ -64,11 +68,11 @@ def main():
                 continue
             auto_v, auto_ms = used.value, ms.value
             res = {}
-            for v in range(N_VARIANTS):
-                if names[v] == "?":
+            for v in list(range(N_VARIANTS)) + (kpart_ids if k == 3 and size <= 8 and batch <= 32 else []):
+                if names[v] == "?" or not names[v].startswith(f"conv{k}x{k}") or NATIVE_WIDTH.get(names[v].split("_k")[0], size) != size:
                     continue
                 rc = lib.mvlm_conv_bench(ctx.handle, batch, cin, cout, k, size, flags, v, args.iters, C.byref(ms), C.byref(used))
-                if rc == 0 and names[v].startswith(f"conv{k}x{k}") and NATIVE_WIDTH.get(names[v], size) == size:
+                if rc == 0:
                     res[names[v]] = round(ms.value * 1e3, 2)
             best = min(res, key=res.get)
             flop = 2.0 * cin * cout * k * k * size * size * batch
@@ -111,7 +115,7 @@ def write_header(table, ids):
              "// where a measured variant beats pick_variant()'s rules by more than 3 %.  {ksize, cin_pad, cout_pad, size, batch, variant};",
              "// sorted; the dispatcher uses the entry of the smallest tuned batch >= the launch's batch for the same shape.",
              "#ifndef MVLM_CONV_TUNED_H", "#define MVLM_CONV_TUNED_H",
-             "struct ConvTuned { short ksize, cin_pad, cout_pad, size, batch; signed char variant; };",
+             "struct ConvTuned { short ksize, cin_pad, cout_pad, size, batch, variant; };",
              "static const ConvTuned MVLM_CONV_TUNED[] = {"]
     n = 0
     for key in sorted(rows):
