@@ -145,7 +145,16 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
                                               StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT], int woff16,
                                               const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16]) {
     constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
-    constexpr int HALF = C::KSTEPS / 2;
+    // staging schedule of the next chunk: loads issued over the first ISSUE_SPAN k-steps, LDS writes over the last WRITE_SPAN
+#if !defined(MVLM_STAGE_ISSUE_DIV)
+#define MVLM_STAGE_ISSUE_DIV 2
+#endif
+#if !defined(MVLM_STAGE_WRITE_DIV)
+#define MVLM_STAGE_WRITE_DIV 2
+#endif
+    constexpr int ISSUE_SPAN = C::KSTEPS / MVLM_STAGE_ISSUE_DIV > 0 ? C::KSTEPS / MVLM_STAGE_ISSUE_DIV : 1;
+    constexpr int WRITE_SPAN = C::KSTEPS / MVLM_STAGE_WRITE_DIV > 0 ? C::KSTEPS / MVLM_STAGE_WRITE_DIV : 1;
+    constexpr int WRITE_START = C::KSTEPS - WRITE_SPAN;
     float av[2][C::MT], bv[2][C::NT];
     float a16 = 0.f, b16[C::NT16];  // 16-row strip: operands of one tap's four channels (two k-steps)
 #pragma unroll
@@ -188,10 +197,10 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             static_for<0, T_TOT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
 #if !defined(MVLM_ABLATE_NO_LOADS)
-                if constexpr ((t * HALF) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r, st_next);
+                if constexpr ((t * ISSUE_SPAN) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r, st_next);
 #endif
 #if !defined(MVLM_ABLATE_NO_WRITES)
-                if constexpr (HALF + (t * HALF) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
+                if constexpr (WRITE_START + (t * WRITE_SPAN) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
 #endif
             });
             __builtin_amdgcn_sched_barrier(0);
