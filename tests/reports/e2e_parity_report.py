@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end parity report at a BASELINE size: GPU path vs CPU oracle on the same mesh, poses,
-weights and RNG seed.  Run on the GPU box.  usage: e2e_parity_report.py [n_views] [grid] [dtu3d|bu3dfe]   (RGB+depth networks: 73 / 84 landmarks)"""
+weights and RNG seed.  Test infrastructure (imports oracle/); run on the GPU box.
+usage: tests/reports/e2e_parity_report.py [n_views] [grid] [dtu3d|bu3dfe]   (RGB+depth networks: 73 / 84 landmarks)"""
 import contextlib
 import io
 import sys
@@ -9,7 +10,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from mvlm_amd import pipeline, weights  # noqa: E402
 from mvlm_amd.utils.mesh_io import load_obj  # noqa: E402
 from mvlm_amd.utils.synthetic import write_face_like_obj  # noqa: E402

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Report how far the HIP network is from the CPU oracle (torch fp32, oneDNN): heatmap
-deviation and argmax differences.  Run on the GPU box.  usage: parity_stats.py [n_views]"""
+deviation and argmax differences.  Test infrastructure (imports oracle/); run on the GPU box.
+usage: tests/reports/parity_stats.py [n_views]"""
 import sys
 from pathlib import Path
 
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))  # tests/ (conftest helpers)
 from conftest import seeded_images  # noqa: E402
 from mvlm_amd import arch, weights  # noqa: E402
 from mvlm_amd.prediction import BU3DFEPredictor, DTU3DPredictor  # noqa: E402
