@@ -215,6 +215,8 @@ def main():
     # MVLM_BENCH_FORCE_DIST=1: take the multi-rank path (process group, sharded pipeline, collectives) with whatever
     # world size there is - under torch.distributed.run --nproc-per-node 1 this rehearses RCCL itself on a one-GPU box
     sharded = world > 1 or (os.environ.get("MVLM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if sharded and world == 1:
+        os.environ["MVLM_DIST_WORLD_OF_ONE"] = "1"  # mvlm_amd.parallel then runs its collectives in the group of one
     if sharded:
         import torch.distributed as dist
 

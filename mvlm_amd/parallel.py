@@ -9,15 +9,21 @@ quantile filter and the RANSAC draws address views by position.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
 def is_distributed() -> bool:
+    """A process group with more than one rank exists.  MVLM_DIST_WORLD_OF_ONE=1 also counts a group of ONE rank: the
+    rehearsal of the sharded path (same collectives, tensors and devices) over RCCL on a one-GPU box."""
     try:
         import torch.distributed as dist
     except Exception:  # noqa: BLE001
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MVLM_DIST_WORLD_OF_ONE") == "1"
 
 
 def rank_world() -> tuple[int, int]:
