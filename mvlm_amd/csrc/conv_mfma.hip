@@ -31,6 +31,7 @@
 //   (paulsenpredictor.py:123) so the [N,NL,256,256] heatmaps never reach HBM.
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "common.h"
 #include "conv_kernel.h"   // Cfg<> (tile geometry) for the compile-time queries below; kernels are not instantiated here
@@ -119,10 +120,14 @@ int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt) {
 const char* mvlm_conv_variant_name_impl(int v) {
     if (v == MVLM_CONV_VARIANT_FAST) return "conv3x3_bf16x3_t8x32";
     if (v >= 256 && v < 1024) {
-        static std::string names[4][256];
-        std::string& n = names[v >> 8][v & 255];
-        if (n.empty()) n = std::string(mvlm_conv_variant_name_impl(v & 255)) + "_k" + std::to_string(1 << (v >> 8));
-        return n.c_str();
+        // built once (thread-safe static initialisation): "<split-K variant>_k<parts>"
+        static const std::vector<std::string> names = [] {
+            std::vector<std::string> t(1024);
+            for (int id = 256; id < 1024; ++id)
+                t[size_t(id)] = std::string(mvlm_conv_variant_name_impl(id & 255)) + "_k" + std::to_string(1 << (id >> 8));
+            return t;
+        }();
+        return names[size_t(v)].c_str();
     }
     switch (v) {
 #define X(id, name, ...) \
