@@ -184,7 +184,10 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
         // two MFMAs first, then this step's share of the staging work, then the rest: the side
         // work's LDS / VMEM operations complete in the shadow of the remaining MFMAs instead of
         // being waited for at the next step's lgkmcnt(0)
-        constexpr int LEAD = (C::MT * C::NT >= 4) ? 2 : 1;
+#if !defined(MVLM_MFMA_LEAD)
+#define MVLM_MFMA_LEAD 2
+#endif
+        constexpr int LEAD = (C::MT * C::NT >= 4) ? (MVLM_MFMA_LEAD < C::MT * C::NT ? MVLM_MFMA_LEAD : C::MT * C::NT) : 1;
         static_for<0, C::MT * C::NT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int m = i / C::NT, n = i % C::NT;
