@@ -1,5 +1,7 @@
 // Context, mesh upload and the single-convolution test hook of the C ABI
 // (include/mvlm_hip.h).
+#include <cstring>
+
 #include "common.h"
 
 void* mvlm_ctx::get_scratch(const char* name, size_t bytes) {
@@ -52,7 +54,16 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
         if (ctx->kparts_ws[i]) hipFree(ctx->kparts_ws[i]);
         if (ctx->kparts_cnt[i]) hipFree(ctx->kparts_cnt[i]);
     }
-    for (auto& e : ctx->mesh_pool) hipFree(e.first);
+    for (auto& e : ctx->mesh_pool) {
+        hipFree(e.p);
+        if (e.freed) hipEventDestroy(e.freed);
+    }
+    for (hipEvent_t e : ctx->event_free) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->upload_stage[i]) hipHostFree(ctx->upload_stage[i]);
+        if (ctx->upload_stage_done[i]) hipEventDestroy(ctx->upload_stage_done[i]);
+    }
+    if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
     if (ctx->render_overflow_host) hipHostFree(ctx->render_overflow_host);
     for (auto e : ctx->cnn.event_pool)
         if (e) hipEventDestroy(e);
@@ -92,41 +103,80 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     for (long i = 0; i < 3l * n_tris; ++i)
         MVLM_REQUIRE(ctx, tris_host[i] >= 0 && tris_host[i] < n_verts, "mesh_upload: triangle index out of range");
     MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    // Sizes and the pinned staging slot (two slots alternate; a slot is reused once the copies out of it are done)
+    if (!ctx->upload_stream) MVLM_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    const bool with_tex = tex_host && uvs_host;
+    const void* src[4] = {verts_host, uvs_host, tris_host, with_tex ? tex_host : nullptr};
+    const size_t bytes[4] = {size_t(n_verts) * 12, uvs_host ? size_t(n_verts) * 8 : 0, size_t(n_tris) * 12,
+                             with_tex ? size_t(tex_h) * tex_w * 3 : 0};
+    size_t off[4], total = 0;
+    for (int i = 0; i < 4; ++i) {
+        off[i] = total;
+        total += (bytes[i] + 255) / 256 * 256;
+    }
+    const int slot = ctx->upload_stage_next;
+    ctx->upload_stage_next ^= 1;
+    if (ctx->upload_stage_done[slot]) MVLM_CHECK_HIP(ctx, hipEventSynchronize(ctx->upload_stage_done[slot]));
+    if (ctx->upload_stage_cap[slot] < total) {
+        if (ctx->upload_stage[slot]) (void)hipHostFree(ctx->upload_stage[slot]);
+        ctx->upload_stage[slot] = nullptr;
+        ctx->upload_stage_cap[slot] = 0;
+        const size_t cap = (total + (size_t(4) << 20)) / (size_t(4) << 20) * (size_t(4) << 20);
+        MVLM_CHECK_HIP(ctx, hipHostMalloc(&ctx->upload_stage[slot], cap, hipHostMallocDefault));
+        ctx->upload_stage_cap[slot] = cap;
+    }
+    auto* stage = static_cast<unsigned char*>(ctx->upload_stage[slot]);
+    for (int i = 0; i < 4; ++i)
+        if (bytes[i]) std::memcpy(stage + off[i], src[i], bytes[i]);
+
     auto* m = new mvlm_mesh();
     m->n_verts = n_verts;
     m->n_tris = n_tris;
-    // a recycled buffer may still be read by work enqueued for the mesh that owned it
-    if (!ctx->mesh_pool.empty()) MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    auto up = [&](void** dst, size_t* cap, const void* src, size_t bytes) -> bool {
-        int best = -1;
-        for (int i = 0; i < int(ctx->mesh_pool.size()); ++i) {
-            const size_t c = ctx->mesh_pool[i].second;
-            if (c >= bytes && c <= 4 * bytes + (1u << 20) && (best < 0 || c < ctx->mesh_pool[best].second)) best = i;
-        }
-        if (best >= 0) {
-            *dst = ctx->mesh_pool[best].first;
-            *cap = ctx->mesh_pool[best].second;
-            ctx->mesh_pool_bytes -= *cap;
-            ctx->mesh_pool.erase(ctx->mesh_pool.begin() + best);
-        } else {
-            *cap = (bytes + 65535) / 65536 * 65536;
-            if (hipMalloc(dst, *cap) != hipSuccess) {
-                *dst = nullptr;
-                *cap = 0;
-                return false;
+    void** dst[4] = {(void**)&m->verts, (void**)&m->uvs, (void**)&m->tris, (void**)&m->tex};
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; ++i) {
+        if (!bytes[i]) continue;
+        // the OLDEST pooled buffer that fits: its previous owner's work finished long ago, so the wait below is a no-op
+        // and the copy really runs beside the current scan's kernels
+        int pick = -1;
+        for (int k = 0; k < int(ctx->mesh_pool.size()); ++k) {
+            const size_t c = ctx->mesh_pool[size_t(k)].cap;
+            if (c >= bytes[i] && c <= 4 * bytes[i] + (1u << 20)) {
+                pick = k;
+                break;
             }
         }
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
-    };
-    bool ok = up((void**)&m->verts, &m->cap[0], verts_host, size_t(n_verts) * 12) &&
-              up((void**)&m->tris, &m->cap[2], tris_host, size_t(n_tris) * 12);
-    if (ok && uvs_host) ok = up((void**)&m->uvs, &m->cap[1], uvs_host, size_t(n_verts) * 8);
-    if (ok && tex_host && uvs_host) {
-        ok = up((void**)&m->tex, &m->cap[3], tex_host, size_t(tex_h) * tex_w * 3);
+        if (pick >= 0) {
+            const auto e = ctx->mesh_pool[size_t(pick)];
+            ctx->mesh_pool.erase(ctx->mesh_pool.begin() + pick);
+            ctx->mesh_pool_bytes -= e.cap;
+            *dst[i] = e.p;
+            m->cap[i] = e.cap;
+            m->waited[i] = e.freed;  // returned to the event list with the mesh
+            if (e.freed && hipStreamWaitEvent(ctx->upload_stream, e.freed, 0) != hipSuccess) ok = false;
+        } else {
+            m->cap[i] = (bytes[i] + 65535) / 65536 * 65536;
+            if (hipMalloc(dst[i], m->cap[i]) != hipSuccess) {
+                *dst[i] = nullptr;
+                m->cap[i] = 0;
+                ok = false;
+            }
+        }
+        if (ok && hipMemcpyAsync(*dst[i], stage + off[i], bytes[i], hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) ok = false;
+    }
+    if (with_tex) {
         m->tex_h = tex_h;
         m->tex_w = tex_w;
     }
+    if (ok) {
+        if (!ctx->upload_stage_done[slot]) ctx->upload_stage_done[slot] = ctx->take_event();
+        m->ready = ctx->take_event();
+        ok = ctx->upload_stage_done[slot] && m->ready &&
+             hipEventRecord(ctx->upload_stage_done[slot], ctx->upload_stream) == hipSuccess &&
+             hipEventRecord(m->ready, ctx->upload_stream) == hipSuccess;
+    }
     if (!ok) {
+        (void)hipStreamSynchronize(ctx->upload_stream);
         mvlm_mesh_free(nullptr, m);
         return ctx->fail("mesh_upload: device allocation / copy failed");
     }
@@ -134,24 +184,37 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     return 0;
 }
 
-// ctx == NULL (or a pool that is full): plain hipFree
+// Buffers go back to the context's pool together with an event on the launch stream: whatever was enqueued for this
+// mesh before the free may still read them.  ctx == NULL (or a pool that is full): plain hipFree (which waits for the device).
 extern "C" void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* m) {
     if (!m) return;
     void* bufs[4] = {m->verts, m->uvs, m->tris, m->tex};
     constexpr size_t POOL_MAX_BYTES = size_t(1) << 30;
     constexpr size_t POOL_MAX_ENTRIES = 32;
+    hipEvent_t spare[5] = {m->ready, m->waited[0], m->waited[1], m->waited[2], m->waited[3]};
     if (ctx) {
         std::lock_guard<std::mutex> lock(ctx->mu);
+        (void)hipSetDevice(ctx->device);
         for (int i = 0; i < 4; ++i)
             if (bufs[i] && m->cap[i] && ctx->mesh_pool.size() < POOL_MAX_ENTRIES &&
                 ctx->mesh_pool_bytes + m->cap[i] <= POOL_MAX_BYTES) {
-                ctx->mesh_pool.emplace_back(bufs[i], m->cap[i]);
+                hipEvent_t ev = ctx->take_event();
+                if (!ev || hipEventRecord(ev, ctx->stream) != hipSuccess) {  // no event: keep the plain (synchronising) free
+                    if (ev) ctx->event_free.push_back(ev);
+                    continue;
+                }
+                ctx->mesh_pool.push_back({bufs[i], m->cap[i], ev});
                 ctx->mesh_pool_bytes += m->cap[i];
                 bufs[i] = nullptr;
             }
+        for (hipEvent_t e : spare)
+            if (e) ctx->event_free.push_back(e);
+    } else {
+        for (hipEvent_t e : spare)
+            if (e) (void)hipEventDestroy(e);
     }
     for (void* b : bufs)
-        if (b) hipFree(b);
+        if (b) (void)hipFree(b);
     delete m;
 }
 

@@ -161,6 +161,9 @@ struct mvlm_mesh {
     uint8_t* tex = nullptr;   // [H,W,3] or null
     int n_verts = 0, n_tris = 0, tex_h = 0, tex_w = 0;
     size_t cap[4] = {0, 0, 0, 0};  // allocation sizes of verts / uvs / tris / tex (for the ctx's mesh pool)
+    // recorded on the context's upload stream behind the four host-to-device copies; every consumer's stream waits for it
+    hipEvent_t ready = nullptr;
+    hipEvent_t waited[4] = {nullptr, nullptr, nullptr, nullptr};  // "previous owner is done" events of recycled buffers
 };
 
 struct RenderProfileRec {
@@ -192,14 +195,43 @@ struct mvlm_ctx {
     size_t render_event_cursor = 0;
     // device buffers of freed meshes, reused by the next upload: a folder of scans would otherwise pay
     // four hipMalloc + four (device-synchronising) hipFree per scan
-    std::vector<std::pair<void*, size_t>> mesh_pool;
+    struct PoolEntry {
+        void* p;
+        size_t cap;
+        hipEvent_t freed;  // recorded on the launch stream when the owning mesh was freed: work enqueued before may read p
+    };
+    std::vector<PoolEntry> mesh_pool;  // oldest first
     size_t mesh_pool_bytes = 0;
+    // mesh uploads: pinned staging (two slots) -> hipMemcpyAsync on a stream of their own, so a reader thread's upload of
+    // the next scan runs beside the current scan's kernels and never makes a host wait for the launch stream
+    hipStream_t upload_stream = nullptr;
+    void* upload_stage[2] = {nullptr, nullptr};
+    size_t upload_stage_cap[2] = {0, 0};
+    hipEvent_t upload_stage_done[2] = {nullptr, nullptr};
+    int upload_stage_next = 0;
+    std::vector<hipEvent_t> event_free;  // recycled (timing-disabled) events
+    hipEvent_t take_event() {
+        if (!event_free.empty()) {
+            hipEvent_t e = event_free.back();
+            event_free.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        return e;
+    }
     int fail(const std::string& m) {
         err = m;
         return 1;
     }
     void* get_scratch(const char* name, size_t bytes);
 };
+
+// a mesh's device copy is complete once its `ready` event has fired: consumers make their stream wait for it
+inline int mvlm_mesh_wait_ready(mvlm_ctx* ctx, const mvlm_mesh* m, hipStream_t stream) {
+    if (m->ready && hipStreamWaitEvent(stream, m->ready, 0) != hipSuccess) return ctx->fail("mesh: hipStreamWaitEvent failed");
+    return 0;
+}
 
 // conv_mfma.hip
 constexpr long MVLM_KPARTS_MAX_TILES = 2048;  // output tiles of a launch that divides K over workgroups

@@ -201,6 +201,7 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, mesh && rot_host && out_dev && n_views > 0, "render: bad arguments");
     MVLM_REQUIRE(ctx, mesh->n_verts > 0 && mesh->n_tris > 0, "render: empty mesh");
+    if (mvlm_mesh_wait_ready(ctx, mesh, ctx->stream)) return 1;  // the upload runs on a stream of its own
     const int V = mesh->n_verts, T = mesh->n_tris;
     const int cap = 4 * T + 16384;  // tile-list entries per view; larger lists raise an error
     auto* tv = static_cast<rm_vert*>(ctx->get_scratch("raster.tv", size_t(n_views) * V * sizeof(rm_vert)));

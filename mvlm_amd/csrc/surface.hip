@@ -235,6 +235,7 @@ extern "C" int mvlm_clip_rays_to_mesh(mvlm_ctx* ctx, const mvlm_mesh* mesh, cons
     MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, mesh && starts_dev && ends_dev && new_ends_dev && n_rays > 0, "clip_rays_to_mesh: bad arguments");
     MVLM_REQUIRE(ctx, mesh->n_tris > 0, "clip_rays_to_mesh: empty mesh");
+    if (mvlm_mesh_wait_ready(ctx, mesh, ctx->stream)) return 1;
     const int groups = (n_rays + RAYS_PER_GROUP - 1) / RAYS_PER_GROUP;
     hipLaunchKernelGGL(clip_rays_kernel, dim3(groups), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris, mesh->n_tris,
                        starts_dev, ends_dev, n_rays, new_ends_dev, hit_dev);
@@ -247,6 +248,7 @@ extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, con
     MVLM_ENTER(ctx);
     MVLM_REQUIRE(ctx, mesh && pts_dev && out_dev && n_points > 0, "project_to_surface: bad arguments");
     MVLM_REQUIRE(ctx, mesh->n_tris > 0, "project_to_surface: empty mesh");
+    if (mvlm_mesh_wait_ready(ctx, mesh, ctx->stream)) return 1;
     const int n_chunks = (mesh->n_tris + PROJECT_CHUNK - 1) / PROJECT_CHUNK;
     auto* part_d = static_cast<double*>(ctx->get_scratch("project.part_d", size_t(n_points) * n_chunks * sizeof(double)));
     auto* part_t = static_cast<int*>(ctx->get_scratch("project.part_t", size_t(n_points) * n_chunks * sizeof(int)));

@@ -15,6 +15,7 @@ is driven through the reference's numpy slot protocol instead.
 from __future__ import annotations
 
 import abc
+import os
 import time
 from pathlib import Path
 
@@ -23,6 +24,7 @@ import numpy as np
 from .. import parallel
 from ..prediction.paulsenpredictor import HipPaulsenModel
 from ..utils.estimator3d import HipEstimator3D
+from ..utils.hostmem import retain_freed_host_memory
 from ..utils.render3d import HipRenderer3D
 
 __all__ = ["Pipeline"]
@@ -91,6 +93,7 @@ class Pipeline(abc.ABC):
         # reference's live pipeline has none (it renders the mesh as-is)
         self.pre_align: dict | None = None
 
+        retain_freed_host_memory()  # scans come and go: keep their host pages (utils/hostmem.py; MVLM_HOST_MALLOC_TUNING=0 opts out)
         if shard_views:
             # one process per GPU: collectives (RCCL) and the allocator must use THIS rank's device, not cuda:0
             import torch
@@ -282,18 +285,21 @@ class Pipeline(abc.ABC):
         self.last_error = error
         return landmarks, error
 
-    def predict_files(self, files, prefetch: int = 2):
+    def predict_files(self, files, prefetch: int = 2, readers: int | None = None):
         """``predict_one_file`` over many scans, yielding ``(file, landmarks | None)`` in order.
 
         The reference's CLI loops ``predict_one_file`` (main.py:55-62), paying file ingest and GPU
         work back to back.  Here a reader thread parses the next ``prefetch`` OBJ/JPEG pairs
         (native reader + libjpeg, both outside the GIL) while the GPU works on the current scan,
-        so a folder runs at the GPU rate.  Results equal the sequential loop's: poses and RANSAC
-        draws are taken on the calling thread in file order, and every scan gets the same
-        post-step (ray dump) as ``predict_one_file``."""
+        so a folder runs at the GPU rate.  With few views per scan (the reference's default 8) one
+        reader is slower than the GPU: ``readers`` threads (default: a quarter of the host's cores,
+        1..4) parse ``max(prefetch, readers + 1)`` scans ahead; delivery stays in file order.  Results
+        equal the sequential loop's: poses and RANSAC draws are taken on the calling thread in file
+        order, and every scan gets the same post-step (ray dump) as ``predict_one_file``."""
         from concurrent.futures import ThreadPoolExecutor
 
         from ..utils.mesh_io import load_obj
+        from ..utils.render3d import upload_mesh
 
         files = [Path(f) for f in files]
         if self.predictor_2d is None:
@@ -306,9 +312,18 @@ class Pipeline(abc.ABC):
         def ingest(f: Path):
             if not f.exists():
                 return None
-            return load_obj(self.renderer_3d._check_file(f))
+            mesh = load_obj(self.renderer_3d._check_file(f))
+            if mesh.n_tris > 0:
+                # device copy from the reader thread too: pinned staging + a copy stream of the library's own, so the
+                # transfer runs beside the current scan's kernels (mvlm_mesh_upload); the renderer waits for its event
+                upload_mesh(self.renderer_3d.ctx, mesh)
+            return mesh
 
-        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvlm-ingest") as pool:
+        if readers is None:
+            readers = min(4, max(1, (os.cpu_count() or 4) // 4))
+        readers = max(1, int(readers))
+        prefetch = max(int(prefetch), readers + 1)
+        with ThreadPoolExecutor(max_workers=readers, thread_name_prefix="mvlm-ingest") as pool:
             pending = [pool.submit(ingest, f) for f in files[:prefetch]]
             for i, f in enumerate(files):
                 if i + prefetch < len(files):

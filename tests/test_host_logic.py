@@ -400,3 +400,18 @@ def test_visualize_image_stack_png_dump(tmp_path):
     me.render_image_folder = tmp_path / "missing"
     with pytest.raises(ValueError, match="does not exist"):
         Pipeline.visualize_image_stack(me, stack, tmp_path / "scan.obj")
+
+
+def test_host_allocator_hint_is_idempotent_and_optional(monkeypatch):
+    """utils/hostmem.py: applied once per process; MVLM_HOST_MALLOC_TUNING=0 switches it off."""
+    from mvlm_amd.utils import hostmem
+
+    monkeypatch.setattr(hostmem, "_applied", None)
+    monkeypatch.setenv("MVLM_HOST_MALLOC_TUNING", "0")
+    assert hostmem.retain_freed_host_memory() is False
+    monkeypatch.setattr(hostmem, "_applied", None)
+    monkeypatch.delenv("MVLM_HOST_MALLOC_TUNING")
+    first = hostmem.retain_freed_host_memory()
+    assert first in (True, False) and hostmem.retain_freed_host_memory() is first
+    a = np.ones(4 << 20, np.uint8)  # allocations keep working either way
+    assert int(a.sum()) == 4 << 20

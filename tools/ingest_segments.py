@@ -1,0 +1,30 @@
+import sys, time, tempfile
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from mvlm_amd import pipeline
+from mvlm_amd.utils.synthetic import write_face_like_obj
+from mvlm_amd.utils.mesh_io import load_obj
+from mvlm_amd.utils.render3d import upload_mesh
+if len(sys.argv) > 1 and sys.argv[1] == "mallopt":
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    print("mallopt mmap", libc.mallopt(-3, 32 << 20), "trim", libc.mallopt(-1, 1 << 30))
+d = Path(tempfile.mkdtemp())
+obj = write_face_like_obj(d / "face.obj", grid=224, tex_size=2048, seed=0)
+pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:0", image_mode="depth", verbose=False)
+for _ in range(3):
+    pipe.predict_one_file(obj)
+ctx = pipe.renderer_3d.ctx
+def T(): torch.cuda.synchronize(); return time.perf_counter()
+for it in range(4):
+    t0 = T(); mesh = load_obj(obj); t1 = T()
+    upload_mesh(ctx, mesh); t2 = time.perf_counter(); torch.cuda.synchronize(); t3 = time.perf_counter()
+    poses = pipe.renderer_3d.generate_3d_transformations()
+    t4 = T(); lm, _ = pipe.predict_mesh_device(mesh, poses); t5 = T()
+    pipe._after_prediction(obj, lm); t6 = T()
+    del mesh; t7 = T()
+    print(f"load {1e3*(t1-t0):.1f}  upload call {1e3*(t2-t1):.1f} (+{1e3*(t3-t2):.1f} until done)  predict_mesh_device {1e3*(t5-t4):.1f}  after {1e3*(t6-t5):.2f}  del {1e3*(t7-t6):.2f}")
+t0 = T()
+for _ in range(5): pipe.predict_one_file(obj)
+print("predict_one_file avg", 1e3*(T()-t0)/5, pipe.timings)
