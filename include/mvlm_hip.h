@@ -69,7 +69,11 @@ int mvlm_mesh_read(const char* path, mvlm_obj** out, char* err, int err_len);
 /* ---- mesh (replaces utils3d.py:10-85 obj_to_actor's upload half) ---------------- */
 /* verts f32[V,3], uvs f32[V,2] or NULL, tris i32[T,3], tex u8[H,W,3] (row 0 = top of
  * the image file) or NULL (=> pure white mesh, utils3d.py:58-64).  Host pointers;
- * the data is copied to the device. */
+ * the data is copied into pinned staging before the call returns (the host arrays are
+ * the caller's again) and travels to the device asynchronously on a copy stream of
+ * the context's own; mvlm_render / mvlm_project_to_surface / mvlm_clip_rays_to_mesh
+ * wait for it on their stream.  May be called from another thread than the one that
+ * launches work (a reader thread uploading the next scan). */
 int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
                      const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
                      mvlm_mesh** out);
