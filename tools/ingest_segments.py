@@ -1,7 +1,11 @@
+#!/usr/bin/env python3
+"""Wall-time segments of one scan at the reference's default 8 views (run on the GPU box): parse, upload call, device
+pass, post-step, dropping the mesh.  usage: tools/ingest_segments.py [mallopt]   (mallopt: apply the allocator hint by hand
+first - Pipeline applies it anyway unless MVLM_HOST_MALLOC_TUNING=0)"""
 import sys, time, tempfile
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mvlm_amd import pipeline
 from mvlm_amd.utils.synthetic import write_face_like_obj
 from mvlm_amd.utils.mesh_io import load_obj
