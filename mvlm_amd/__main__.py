@@ -31,6 +31,9 @@ def main(argv=None) -> int:
     parser.add_argument("--weights", type=str, default=None,
                         help='checkpoint path, or "synthetic[:seed]" (no checkpoint is reachable offline)')
     parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--precision", choices=("exact", "fast"), default="exact",
+                        help="exact: fp32 on the matrix cores (default, the parity path); fast: the big 3x3 layers on "
+                             "bf16x3-split operands (fp32-accurate, not bit-identical; DESIGN.md 4.1b)")
     args = parser.parse_args(argv)
     if args.out is None:
         args.out = args.path
@@ -65,7 +68,8 @@ def main(argv=None) -> int:
     for pname in [p for p in args.pipelines.split(",") if p]:
         print(f"Pipeline: {pname}")
         dm = pipeline.create_pipeline(pname, render_image_stack=args.visualize_method, n_views=args.n_views,
-                                      weights=args.weights, device=args.device)
+                                      weights=args.weights, device=args.device,
+                                      **({"precision": "fast"} if args.precision == "fast" else {}))
         for file, landmarks in dm.predict_files(obj_files):  # ingest of the next scan overlaps the GPU work
             print(f"Current file: {file}")
             if landmarks is None:

@@ -1,0 +1,31 @@
+import sys, time, tempfile, shutil
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mvlm_amd import pipeline
+from mvlm_amd.utils.synthetic import write_face_like_obj
+d = Path(tempfile.mkdtemp())
+first = write_face_like_obj(d / "scan0.obj", grid=224, tex_size=2048, seed=0)
+files = [first]
+for i in range(1, 16):
+    f = d / f"scan{i}.obj"; shutil.copy(first, f); shutil.copy(first.with_suffix(".jpg"), f.with_suffix(".jpg")); files.append(f)
+pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:0", image_mode="depth", verbose=False)
+for _ in range(3): pipe.predict_one_file(first)
+print(pipe.predictor_2d.execution_stats())
+t_prev = time.perf_counter(); ts = []
+for f, lm in pipe.predict_files(files):
+    t = time.perf_counter(); ts.append(1e3 * (t - t_prev)); t_prev = t
+print("per scan ms:", " ".join(f"{v:.1f}" for v in ts))
+print(pipe.predictor_2d.execution_stats(), pipe.timings)
+# same mesh repeatedly through predict_mesh_device (the bench's step)
+from mvlm_amd.utils.mesh_io import load_obj
+mesh = load_obj(first); poses = pipe.renderer_3d.generate_3d_transformations()
+for _ in range(3): pipe.predict_mesh_device(mesh, poses)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): pipe.predict_mesh_device(mesh, poses)
+torch.cuda.synchronize(); print("same mesh step ms", 1e3 * (time.perf_counter() - t0) / 10)
+meshes = [load_obj(f) for f in files[:8]]
+for m in meshes: pipe.predict_mesh_device(m, poses)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for m in meshes: pipe.predict_mesh_device(m, poses)
+torch.cuda.synchronize(); print("different uploaded meshes step ms", 1e3 * (time.perf_counter() - t0) / 8)
