@@ -462,14 +462,20 @@ def test_fast_conv_matches_torch(cin, cout, size, batch, opts):
     assert err < 1e-5 * max(1.0, np.abs(want).max()), err
 
 
-def test_fast_precision_network_close_to_exact():
+@pytest.mark.parametrize("family", ["bu3dfe", "dtu3d"])
+def test_fast_precision_network_close_to_exact(family):
     """precision="fast" on the whole network: heatmaps within 1e-4 of the value range of the exact path's, argmax pixels
-    equal except near-ties; switching back restores the exact path bit for bit."""
+    equal except near-ties; switching back restores the exact path bit for bit.  84 landmarks: conv6 / conv10 / conv7 run
+    on the bf16x3 kernel with padded channels; 73 landmarks: conv7 does (73 -> 80 input channels), conv6 / conv10 stay
+    exact (73 of 128 output channels would waste too much)."""
     from conftest import seeded_images
-    from mvlm_amd.prediction import BU3DFEPredictor
+    from mvlm_amd.prediction import BU3DFEPredictor, DTU3DPredictor
 
     imgs = dev(seeded_images(41, 4))
-    pred = BU3DFEPredictor(image_mode="RGB+depth", weights="synthetic:3", verbose=False)
+    if family == "bu3dfe":
+        pred = BU3DFEPredictor(image_mode="RGB+depth", weights="synthetic:3", verbose=False)
+    else:
+        pred = DTU3DPredictor(image_mode="RGB", weights="synthetic:4", verbose=False)
     exact_heat = pred.heatmaps_device(imgs).clone()
     exact_max = pred.predict_device(imgs).clone()
     pred.set_precision("fast")
@@ -479,6 +485,6 @@ def test_fast_precision_network_close_to_exact():
     dev_heat = (fast_heat - exact_heat).abs().max().item()
     assert 0 < dev_heat < 1e-4 * scale, (dev_heat, scale)          # different arithmetic, fp32-class accuracy
     flips = (~torch.all(fast_max[:, :, :2] == exact_max[:, :, :2], dim=2)).sum().item()
-    assert flips <= 0.03 * 84 * 4, flips
+    assert flips <= 0.03 * pred.get_lm_count() * 4, flips
     pred.set_precision("exact")
     assert torch.equal(pred.predict_device(imgs), exact_max)
