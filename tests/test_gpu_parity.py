@@ -648,6 +648,24 @@ def test_predict_files_equals_the_sequential_loop(tmp_path):
         list(pipe.predict_files([files[0], tmp_path / "bad.obj"]))
 
 
+def test_predict_files_with_reader_pool_and_recycled_buffers(tmp_path):
+    """Several reader threads upload scans of changing size ahead of the GPU: staging slots grow and alternate, device
+    buffers of dropped meshes come back from the pool (oldest first, behind their 'freed' event), and every scan must
+    still give exactly the sequential loop's landmarks - twice over, so the second pass runs entirely on recycled buffers."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    grids = [28, 61, 33, 75, 30, 52, 90, 31]
+    files = [write_face_like_obj(tmp_path / f"s{i}.obj", grid=g, tex_size=32 * (1 + i % 3), seed=i) for i, g in enumerate(grids)]
+    pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:6", image_mode="RGB+depth", verbose=False)
+    np.random.seed(9)
+    want = [pipe.predict_one_file(f) for f in files + files]
+    np.random.seed(9)
+    got = [lm for _, lm in pipe.predict_files(files + files, readers=3)]
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+
+
 def test_geometry_shading_bit_exact_and_config_driven():
     """The build-defined geometry plane: HIP == CPU restatement, and a geometry+depth config selects it."""
     from mvlm_amd import config
