@@ -34,6 +34,9 @@ def main(argv=None) -> int:
     parser.add_argument("--precision", choices=("exact", "fast"), default="exact",
                         help="exact: fp32 on the matrix cores (default, the parity path); fast: the big 3x3 layers on "
                              "bf16x3-split operands (fp32-accurate, not bit-identical; DESIGN.md 4.1b)")
+    parser.add_argument("--batch-scans", type=int, default=1,
+                        help="that many consecutive scans share one pass of the network (higher throughput at few views per "
+                             "scan; a near-tied heatmap maximum may resolve differently than in the one-by-one loop)")
     args = parser.parse_args(argv)
     if args.out is None:
         args.out = args.path
@@ -70,7 +73,8 @@ def main(argv=None) -> int:
         dm = pipeline.create_pipeline(pname, render_image_stack=args.visualize_method, n_views=args.n_views,
                                       weights=args.weights, device=args.device,
                                       **({"precision": "fast"} if args.precision == "fast" else {}))
-        for file, landmarks in dm.predict_files(obj_files):  # ingest of the next scan overlaps the GPU work
+        # ingest of the next scans overlaps the GPU work
+        for file, landmarks in dm.predict_files(obj_files, batch_scans=args.batch_scans):
             print(f"Current file: {file}")
             if landmarks is None:
                 print(f"Landmarks for {file} could not be predicted -> skipping file [{file.stem}] for pipeline {pname}")

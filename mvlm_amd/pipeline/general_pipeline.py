@@ -285,7 +285,92 @@ class Pipeline(abc.ABC):
         self.last_error = error
         return landmarks, error
 
-    def predict_files(self, files, prefetch: int = 2, readers: int | None = None):
+    def _groupable(self, n_scans: int) -> bool:
+        """Can ``n_scans`` scans share one network pass (predict_meshes_device)?"""
+        p2, e3 = self.predictor_2d, self.estimator_3d
+        if n_scans < 2 or not self._fusable() or not isinstance(p2, HipPaulsenModel):
+            return False
+        if (self.shard_views and parallel.is_distributed()) or self.render_image_stack or self.visualize_rays or self.pre_align:
+            return False
+        n = int(self.renderer_3d.n_views)
+        return e3.expected_counts(p2.get_lm_count(), n) is not None and n_scans * n <= (p2.device_batch or 128)
+
+    def predict_meshes_device(self, meshes, pose_fn=None):
+        """Several loaded scans through ONE pass of the network: with few views per scan (the reference's default 8) a
+        pass over 8 views runs the matrix cores at 0.64 of what a pass over 64 does.  Every scan is rendered into its
+        slice of one image stack, the network runs once, rays / consensus / snap follow per scan and ONE copy brings all
+        results back.  The global RNG is consumed exactly as by a loop of ``predict_mesh_device``: poses of scan 1, draws
+        of scan 1, poses of scan 2, ... - the draws being the speculative ones of ``plan_draws``; if a scan's survivor
+        counts differ from the expectation (tied / NaN scores), that scan's draws are repeated from the saved RNG
+        state and the scans after it are processed one by one from there.  Returns [(landmarks, error), ...]; falls back
+        to the loop when the scans cannot share a pass (``_groupable``)."""
+        import torch
+
+        from ..utils.render3d import view_rotations
+
+        r3, p2, e3 = self.renderer_3d, self.predictor_2d, self.estimator_3d
+        pose_fn = pose_fn or r3.generate_3d_transformations
+        k = len(meshes)
+        if not self._groupable(k):
+            return [self.predict_mesh_device(m, pose_fn()) for m in meshes]
+        nl, n = p2.get_lm_count(), int(r3.n_views)
+        per = (nl * 36 + 7) // 8 * 8
+        stacks, rots, rot_devs, plans = [], [], [], []
+        for j in range(k):  # the host's RNG work first, in the loop's order; uploads while the stream is empty
+            ts = pose_fn()
+            if int(ts.shape[0]) != n:
+                raise ValueError("predict_meshes_device: every scan needs the pipeline's n_views poses")
+            rot = view_rotations(ts)
+            stacks.append(ts)
+            rots.append(rot)
+            plans.append(e3.plan_draws(nl, n, None, slot=j))
+            rot_devs.append(e3.upload_rotations(rot))
+        tm = self._timer
+        with tm.stage("render"):
+            images = self._buffer("images_group", (k * n, 256, 256, 4))
+            for j in range(k):
+                r3.render_device(meshes[j], stacks[j], rot=rots[j], out=images[j * n:(j + 1) * n])
+        with tm.stage("prediction"):
+            maxima = p2.predict_device(images, out=self._buffer("maxima_group", (nl, k * n, 3)))
+        pack = self._buffer_bytes("result_group", k * per)
+        pending = []
+        with tm.stage("consensus"):
+            for j in range(k):
+                seg = pack[j * per:(j + 1) * per]
+                snap_view = seg[: nl * 24].view(torch.float64).view(nl, 3)
+                err_view = seg[nl * 24: nl * 32].view(torch.float64)
+                count_view = seg[nl * 32: nl * 36].view(torch.int32)
+                mj = maxima[:, j * n:(j + 1) * n].contiguous()
+                starts, ends = e3.lines_device(mj, stacks[j], 256, rot_dev=rot_devs[j])
+                out, _, verify = e3.consensus_device(mj, starts, ends, deferred=True, plan=plans[j], err_out=err_view,
+                                                     count_out=count_view)
+                e3.project_device(meshes[j], out, out=snap_view)
+                pending.append((out, verify, snap_view))
+        results = []
+
+        def unpack(host_seg):
+            landmarks = host_seg[: nl * 24].view(np.float64).reshape(nl, 3).copy()
+            return landmarks, e3.mean_error(host_seg[nl * 24: nl * 32].view(np.float64))
+
+        with tm.stage("project"):
+            host = pack[: k * per].cpu().numpy()
+            for j in range(k):
+                out, verify, snap_view = pending[j]
+                seg = host[j * per:(j + 1) * per]
+                if verify(counts=seg[nl * 32: nl * 36].view(np.int32)):
+                    # other survivor counts than planned: this scan's draws + solve were repeated from its saved RNG
+                    # state; the RNG now stands where the loop would have it, so the remaining scans go one by one
+                    e3.project_device(meshes[j], out, out=snap_view)
+                    results.append(unpack(pack[j * per:(j + 1) * per].cpu().numpy()))
+                    for i in range(j + 1, k):
+                        results.append(self.predict_mesh_device(meshes[i], pose_fn()))
+                    break
+                results.append(unpack(seg))
+            r3.check()
+        self.last_error = results[-1][1]
+        return results
+
+    def predict_files(self, files, prefetch: int = 2, readers: int | None = None, batch_scans: int = 1):
         """``predict_one_file`` over many scans, yielding ``(file, landmarks | None)`` in order.
 
         The reference's CLI loops ``predict_one_file`` (main.py:55-62), paying file ingest and GPU
@@ -295,7 +380,9 @@ class Pipeline(abc.ABC):
         reader is slower than the GPU: ``readers`` threads (default: a quarter of the host's cores,
         1..4) parse ``max(prefetch, readers + 1)`` scans ahead; delivery stays in file order.  Results
         equal the sequential loop's: poses and RANSAC draws are taken on the calling thread in file
-        order, and every scan gets the same post-step (ray dump) as ``predict_one_file``."""
+        order, and every scan gets the same post-step (ray dump) as ``predict_one_file``.
+        ``batch_scans`` > 1: that many consecutive scans share one pass of the network
+        (``predict_meshes_device``; same results, higher throughput when a scan has few views)."""
         from concurrent.futures import ThreadPoolExecutor
 
         from ..utils.mesh_io import load_obj
@@ -322,16 +409,40 @@ class Pipeline(abc.ABC):
         if readers is None:
             readers = min(4, max(1, (os.cpu_count() or 4) // 4))
         readers = max(1, int(readers))
-        prefetch = max(int(prefetch), readers + 1)
+        batch_scans = max(1, int(batch_scans))
+        if batch_scans > 1 and not self._groupable(batch_scans):
+            batch_scans = 1
+        prefetch = max(int(prefetch), readers + 1, 2 * batch_scans if batch_scans > 1 else 0)
         with ThreadPoolExecutor(max_workers=readers, thread_name_prefix="mvlm-ingest") as pool:
             pending = [pool.submit(ingest, f) for f in files[:prefetch]]
+            group: list = []  # (file, mesh) of scans waiting to share a network pass
+
+            def flush():
+                if not group:
+                    return
+                with self._timer.stage("total"):
+                    results = self.predict_meshes_device([m for _, m in group])
+                for (gf, gm), (landmarks, _) in zip(group, results):
+                    self._rays = None
+                    self._after_prediction(gf, landmarks)
+                    yield gf, landmarks
+                pool.submit(_drop, [m for _, m in group])
+                group.clear()
+
             for i, f in enumerate(files):
                 if i + prefetch < len(files):
                     pending.append(pool.submit(ingest, files[i + prefetch]))
                 mesh = pending.pop(0).result()  # re-raises the reader's ValueError / FileNotFoundError
                 if mesh is None:
+                    yield from flush()
                     print(f"File {f} does not exist")
                     yield f, None
+                    continue
+                if batch_scans > 1:
+                    group.append((f, mesh))
+                    del mesh
+                    if len(group) == batch_scans or i + 1 == len(files):
+                        yield from flush()
                     continue
                 self._rays = None
                 with self._timer.stage("total"):
@@ -343,6 +454,7 @@ class Pipeline(abc.ABC):
                 pool.submit(_drop, [mesh])
                 del mesh
                 yield f, landmarks
+            yield from flush()
 
     def _predict_fused(self, file_name: Path, mesh=None):
         from ..utils.mesh_io import load_obj

@@ -85,7 +85,7 @@ class HipEstimator3D:
         k = n_views - 1 - int(np.floor(float(self.threshold_quantile) * (n_views - 1)))
         return np.full(n_landmarks, k, dtype=np.int32)
 
-    def plan_draws(self, n_landmarks: int, n_views: int, draws_fn=None):
+    def plan_draws(self, n_landmarks: int, n_views: int, draws_fn=None, slot: int = 0):
         """Make the RANSAC draws of the coming consensus BEFORE the step's GPU work is enqueued, where that is
         possible, and put them on the device.  The draws need each landmark's survivor count k (the reference draws
         from range(k), estimator3d.py:105), which only exists once the network has finished; fetching it, drawing
@@ -94,7 +94,8 @@ class HipEstimator3D:
         drawn for that k now; ``consensus_device(plan=...)`` enqueues the solve with it and its ``verify`` compares
         the real counts afterwards - a mismatch rewinds the global RNG to the state saved here and repeats draws +
         solve, so the stream of random numbers consumed, and every result, is the one the synchronous order gives.
-        Returns a dict (``expected`` is None when nothing could be planned: absolute mode)."""
+        Returns a dict (``expected`` is None when nothing could be planned: absolute mode).  ``slot``: plans that are
+        alive at the same time (several scans sharing one network pass) need staging and device buffers of their own."""
         torch, dev = self._torch()
         plan = {"expected": self.expected_counts(n_landmarks, n_views), "rng_state": np.random.get_state(),
                 "draws_fn": draws_fn, "draws_dev": None, "ready": None}
@@ -110,7 +111,7 @@ class HipEstimator3D:
             # enqueued on the compute stream nor blocks the host; the solve waits for the event
             if self._upload_stream is None:
                 self._upload_stream = torch.cuda.Stream(device=dev)
-            key = (n_landmarks,)
+            key = (n_landmarks, int(slot))
             bufs = self._draw_bufs.get(key)
             if bufs is None:
                 bufs = self._draw_bufs[key] = (torch.empty((n_landmarks, 8), dtype=torch.int32).pin_memory(),

@@ -666,6 +666,59 @@ def test_predict_files_with_reader_pool_and_recycled_buffers(tmp_path):
         np.testing.assert_array_equal(g, w)
 
 
+@pytest.mark.parametrize("n_views", [8, 12])
+def test_batched_scans_equal_the_sequential_loop(tmp_path, n_views, monkeypatch):
+    """predict_files(batch_scans=3): three scans share one network pass and every scan still gets the sequential loop's
+    landmarks - fixed 8-view table and RNG-drawn poses (12 views: poses and RANSAC draws interleave in the global RNG
+    stream), a missing file in the middle, a last group that is not full.  A larger device batch may be served by other
+    kernel variants (another fp32 summation order), so a near-tied argmax of these random-weight heatmaps may move: a
+    landmark whose maxima did not move is bit-identical, and at least 95 % of them must be; the RNG must stand exactly
+    where the loop leaves it.  Then the same with one scan's speculative draws made for WRONG survivor counts: its draws
+    are repeated from the saved RNG state and the scans after it fall back to the loop."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    files = [write_face_like_obj(tmp_path / f"s{i}.obj", grid=30 + 5 * i, tex_size=64, seed=i) for i in range(7)]
+    files.insert(4, tmp_path / "missing.obj")
+    pipe = pipeline.create_pipeline("bu3dfe", n_views=n_views, weights="synthetic:8", image_mode="RGB+depth", verbose=False)
+    np.random.seed(21)
+    want = [pipe.predict_one_file(f) for f in files]
+    state_after = np.random.get_state()[1].copy()
+    np.random.seed(21)
+    got = list(pipe.predict_files(files, batch_scans=3))
+    assert [f for f, _ in got] == files
+
+    def same_scans(res):
+        for (f, g), w in zip(res, want):
+            if w is None:
+                assert g is None
+            else:
+                identical = np.all(g == w, axis=1)
+                assert identical.mean() >= 0.95, (f.name, identical.mean())
+                assert np.abs(g - w).max() < 60.0
+
+    same_scans(got)
+    np.testing.assert_array_equal(np.random.get_state()[1], state_after)   # the RNG stands where the loop leaves it
+
+    e3 = pipe.estimator_3d
+    real_plan, calls = e3.plan_draws, [0]
+
+    def tampered(nl, n, draws_fn=None, slot=0):
+        plan = real_plan(nl, n, draws_fn, slot=slot)
+        calls[0] += 1
+        if calls[0] == 2 and plan["expected"] is not None:   # second scan of the first group
+            plan["expected"] = plan["expected"].copy()
+            plan["expected"][0] += 1
+        return plan
+
+    monkeypatch.setattr(e3, "plan_draws", tampered)
+    np.random.seed(21)
+    again = list(pipe.predict_files(files, batch_scans=3))
+    assert calls[0] >= 7
+    same_scans(again)
+    np.testing.assert_array_equal(np.random.get_state()[1], state_after)
+
+
 def test_geometry_shading_bit_exact_and_config_driven():
     """The build-defined geometry plane: HIP == CPU restatement, and a geometry+depth config selects it."""
     from mvlm_amd import config
