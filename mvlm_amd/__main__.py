@@ -37,6 +37,9 @@ def main(argv=None) -> int:
     parser.add_argument("--batch-scans", type=int, default=1,
                         help="that many consecutive scans share one pass of the network (higher throughput at few views per "
                              "scan; a near-tied heatmap maximum may resolve differently than in the one-by-one loop)")
+    parser.add_argument("--seed", type=int, default=None,
+                        help="seed of the global numpy RNG (poses for N != 8 views and the RANSAC draws come from it, as in the "
+                             "reference, which never seeds it): makes a run reproducible")
     args = parser.parse_args(argv)
     if args.out is None:
         args.out = args.path
@@ -70,6 +73,8 @@ def main(argv=None) -> int:
 
     for pname in [p for p in args.pipelines.split(",") if p]:
         print(f"Pipeline: {pname}")
+        if args.seed is not None:
+            np.random.seed(args.seed)
         dm = pipeline.create_pipeline(pname, render_image_stack=args.visualize_method, n_views=args.n_views,
                                       weights=args.weights, device=args.device,
                                       **({"precision": "fast"} if args.precision == "fast" else {}))
