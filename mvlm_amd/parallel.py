@@ -79,8 +79,10 @@ def broadcast_array(arr: np.ndarray | None, shape: tuple, device=None, src: int 
     return out.astype(np.float32) if host[n] == 1.0 else out
 
 
-def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0) -> np.ndarray:
-    """Broadcast a small int32 table (the RANSAC draws) as ONE tensor collective - no pickling."""
+def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0, keep_on_device: bool = False):
+    """Broadcast a small int32 table (the RANSAC draws) as ONE tensor collective - no pickling.
+    ``keep_on_device``: under RCCL return the device tensor itself (the consumer is a kernel on this rank's GPU: no
+    copy back to the host, no wait for the collective on the host); under gloo the host array as always."""
     if not is_distributed():
         return arr
     import torch
@@ -90,6 +92,8 @@ def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0) 
     if dist.get_rank() == src:
         t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)))
     dist.broadcast(t, src=src)
+    if keep_on_device and t.is_cuda:
+        return t
     return t.cpu().numpy()
 
 

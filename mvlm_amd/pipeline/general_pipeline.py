@@ -217,9 +217,11 @@ class Pipeline(abc.ABC):
             # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) and broadcasts the table
             dev_t = torch.device("cuda", self.device)
 
-            def draws_fn(counts):
+            def draws_fn(counts, keep_on_device=False):
                 draws = e3.draw_ransac_indices(counts) if rank == 0 else None
-                return parallel.broadcast_int32(draws, (len(counts), 8), dev_t)
+                return parallel.broadcast_int32(draws, (len(counts), 8), dev_t, keep_on_device=keep_on_device)
+
+            draws_fn.device_result = True  # plan_draws may ask for the collective's device tensor (RCCL)
 
         nl_all = p2.get_lm_count()
         # sharded: the draws come out of a collective, which must not queue up behind this step's network

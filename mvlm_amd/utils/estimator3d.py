@@ -64,6 +64,13 @@ class HipEstimator3D:
     def draw_ransac_indices(self, counts: np.ndarray) -> np.ndarray:
         """The reference draws once per landmark with >= 3 surviving lines, in landmark order, from the
         global numpy RNG (estimator3d.py:105, :174-179).  counts int[NL] -> draws int32[NL,8]."""
+        counts = np.asarray(counts)
+        if len(counts) and int(counts.min()) == int(counts.max()) and int(counts[0]) >= 3:
+            # the usual case (quantile filter, distinct scores: every landmark keeps the same number of lines): ONE call
+            # consumes the global RNG exactly as the per-landmark calls do (masked rejection per element, no state
+            # carried between calls; tests/test_host_logic.py checks values and final RNG state) in a tenth of the time -
+            # in the sharded pipeline every rank waits for rank 0's draws
+            return np.random.randint(0, int(counts[0]), size=(len(counts), 8)).astype(np.int32)
         draws = np.zeros((len(counts), 8), dtype=np.int32)
         for lm, k in enumerate(counts):
             k = int(k)
@@ -102,9 +109,20 @@ class HipEstimator3D:
         if plan["expected"] is not None:
             verbose, self.verbose = self.verbose, False  # "Not enough points" is reported by the pass that counts
             try:
-                draws = np.ascontiguousarray((draws_fn or self.draw_ransac_indices)(plan["expected"]), dtype=np.int32)
+                if draws_fn is not None and getattr(draws_fn, "device_result", False):
+                    draws = draws_fn(plan["expected"], keep_on_device=True)
+                else:
+                    draws = (draws_fn or self.draw_ransac_indices)(plan["expected"])
             finally:
                 self.verbose = verbose
+            if torch.is_tensor(draws):
+                # the table came out of a collective on this rank's GPU (sharded pipeline over RCCL): the solve kernel
+                # reads it where it is; the collective is ordered before later work of the current stream
+                if tuple(draws.shape) != (n_landmarks, 8) or draws.dtype != torch.int32:
+                    raise ValueError(f"RANSAC draws must be int32 [{n_landmarks}, 8], got {tuple(draws.shape)} {draws.dtype}")
+                plan["draws_dev"], plan["ready"] = draws.contiguous(), None
+                return plan
+            draws = np.ascontiguousarray(draws, dtype=np.int32)
             if draws.shape != (n_landmarks, 8):
                 raise ValueError(f"RANSAC draws must be [{n_landmarks}, 8], got {draws.shape}")
             # pinned staging buffer + a copy stream of its own: the upload neither waits for the work already

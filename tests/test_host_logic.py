@@ -323,6 +323,36 @@ def test_rng_draw_shortcut_is_the_same_stream():
         assert all(np.array_equal(x, y) for x, y in zip(a, b)) and np.array_equal(sa, sb)
 
 
+def test_one_call_for_all_landmarks_is_the_same_stream():
+    """draw_ransac_indices with equal survivor counts: ONE randint(0, k, size=(NL, 8)) == NL calls of the reference's
+    np.random.choice(range(k), 8, replace=True) (estimator3d.py:105), values and the RNG state afterwards - for every
+    survivor count a view count of the BASELINE configs can produce, and landmark counts 73 / 84 / 478."""
+    from mvlm_amd.utils.estimator3d import HipEstimator3D
+
+    draw = HipEstimator3D.draw_ransac_indices
+    est = HipEstimator3D.__new__(HipEstimator3D)
+    est.verbose = False
+    for nl in (73, 84, 478):
+        for k in (3, 4, 5, 6, 7, 8, 12, 16, 24, 32, 33, 47, 48, 63, 64, 65, 100, 127, 128, 255, 256, 257, 1000):
+            np.random.seed(1000 * nl + k)
+            want = np.stack([np.random.choice(range(k), 8, replace=True) for _ in range(nl)]).astype(np.int32)
+            tail_want = np.random.randint(0, 1 << 30, size=4)
+            np.random.seed(1000 * nl + k)
+            got = draw(est, np.full(nl, k))
+            tail_got = np.random.randint(0, 1 << 30, size=4)
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(tail_got, tail_want)
+    # unequal counts keep the per-landmark path (and its skipping of landmarks with fewer than three lines)
+    counts = np.array([5, 2, 9, 0, 3])
+    np.random.seed(3)
+    want = np.zeros((5, 8), np.int32)
+    for i, k in enumerate(counts):
+        if k >= 3:
+            want[i] = np.random.choice(range(k), 8, replace=True)
+    np.random.seed(3)
+    np.testing.assert_array_equal(draw(est, counts), want)
+
+
 def test_vectorised_rotations_equal_scalar_formulation():
     from mvlm_amd.utils.render3d import _view_rotation_scalar, view_rotations
 
