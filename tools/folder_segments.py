@@ -20,12 +20,12 @@ for f, lm in pipe.predict_files(files):
     t = time.perf_counter(); ts.append(1e3 * (t - t_prev)); t_prev = t
 print("per scan ms:", " ".join(f"{v:.1f}" for v in ts))
 print(pipe.predictor_2d.execution_stats(), pipe.timings)
-for bs in (1, 2, 4, 8, 16):
+for bs, rd in ((1, None), (2, None), (4, None), (8, None), (16, None), (1, 8), (4, 8), (8, 8), (4, 2), (4, 6)):
     list(pipe.predict_files(files[:bs * 2], batch_scans=bs))  # capture the graph of this batch size
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n_done = sum(1 for _ in pipe.predict_files(files, batch_scans=bs))
+    n_done = sum(1 for _ in pipe.predict_files(files, batch_scans=bs, readers=rd))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"batch_scans {bs:2d}: {1e3 * dt / n_done:6.2f} ms per scan  ({8 * n_done / dt:7.1f} views/s, ingest included)")
+    print(f"batch_scans {bs:2d} readers {rd}: {1e3 * dt / n_done:6.2f} ms per scan  ({8 * n_done / dt:7.1f} views/s, ingest included)")
 # same mesh repeatedly through predict_mesh_device (the bench's step)
 from mvlm_amd.utils.mesh_io import load_obj
 mesh = load_obj(first); poses = pipe.renderer_3d.generate_3d_transformations()
@@ -38,3 +38,11 @@ for m in meshes: pipe.predict_mesh_device(m, poses)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for m in meshes: pipe.predict_mesh_device(m, poses)
 torch.cuda.synchronize(); print("different uploaded meshes step ms", 1e3 * (time.perf_counter() - t0) / 8)
+
+for k in (2, 4, 8):
+    group = meshes[:k]
+    for _ in range(3): pipe.predict_meshes_device(group)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): pipe.predict_meshes_device(group)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f"predict_meshes_device, {k} resident scans: {1e3 * dt:.2f} ms per group = {1e3 * dt / k:.2f} ms per scan", {n: round(1e3 * v, 2) for n, v in pipe.timings.items()})
