@@ -240,7 +240,10 @@ extern "C" int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin
     const bool tail16 = ksize == 3 && (cout + 15) / 16 * 16 == 80 && !pre_scale_host && !post_scale_host && !r_dev &&
                         w >= 32 && h % 8 == 0;
     const int cin_pad = (ksize == 1 ? (cin + 7) / 8 * 8 : (cin + 3) / 4 * 4), taps = ksize * ksize;
-    const int cout_pad = tail16 ? (cout + 15) / 16 * 16 : (cout + 31) / 32 * 32;
+    // ... or, with exactly 84 output channels, in a 16-row and a 4-row strip (conv6 / conv10 of the 84-landmark network)
+    const bool tail4 = ksize == 3 && cout == 84 && bias_host && !pre_scale_host && !post_scale_host && !r_dev && !upsample_in &&
+                       w >= 32 && h % 8 == 0;
+    const int cout_pad = tail16 ? (cout + 15) / 16 * 16 : tail4 ? 84 : (cout + 31) / 32 * 32;
     std::vector<float> blob;
     auto push = [&](size_t n) {
         const size_t off = blob.size();
@@ -303,7 +306,7 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
     MVLM_REQUIRE(ctx, ksize == 1 || ksize == 3, "conv_bench: kernel size must be 1 or 3");
     const int cin_pad = (ksize == 1 ? (cin + 7) / 8 * 8 : (cin + 3) / 4 * 4), taps = ksize * ksize;
     const bool plain = (flags & 4) && !(flags & (1 | 2 | 8));
-    const int cout_pad = (plain && (cout + 15) / 16 * 16 == 80) ? 80 : (cout + 31) / 32 * 32;
+    const int cout_pad = (plain && (cout + 15) / 16 * 16 == 80) ? 80 : (plain && ksize == 3 && cout == 84) ? 84 : (cout + 31) / 32 * 32;
     const size_t px = size_t(batch) * size * size;
     const size_t n_w = size_t(taps) * cin_pad * cout_pad, n_vec = size_t(cin_pad) * 2 + size_t(cout_pad) * 3;
     const size_t n_x = px * cin, n_y = px * cout;

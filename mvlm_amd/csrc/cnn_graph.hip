@@ -657,7 +657,9 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
         const int32_t* r = &st.desc[size_t(s) * MVLM_CONV_DESC_INTS];
         if (!r[0]) continue;
         MVLM_REQUIRE(ctx, r[1] > 0 && r[2] > 0 && r[3] >= 1 && r[3] <= 3, "cnn_load: bad conv shape");
-        MVLM_REQUIRE(ctx, r[4] % 4 == 0 && r[4] >= r[1] && r[5] % 16 == 0 && r[5] >= r[2], "cnn_load: bad padding");
+        // output channels: multiples of 16 (32-row tiles, 64 + 16-row strip), or exactly 84 = 64 + 16 + 4 rows
+        MVLM_REQUIRE(ctx, r[4] % 4 == 0 && r[4] >= r[1] && (r[5] % 16 == 0 || (r[5] == 84 && r[2] == 84 && r[3] == 3)) && r[5] >= r[2],
+                     "cnn_load: bad padding");
         const size_t wsz = size_t(r[3]) * r[3] * r[4] * r[5];
         MVLM_REQUIRE(ctx, r[6] >= 0 && size_t(r[6]) + wsz <= n_floats, "cnn_load: weight offset out of range");
         const int offs[5] = {r[7], r[8], r[9], r[10], r[11]};

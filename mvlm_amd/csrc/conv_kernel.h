@@ -47,7 +47,10 @@ struct Cfg {
     static constexpr int MT = COUT_T / 32;  // full 32-row MFMA tiles
     // COUT_T = 32*MT + 16: the last 16 output channels run on v_mfma_f32_16x16x4_f32 (same FLOP rate,
     // half the rows), so a 73-landmark layer pads to 80 rows instead of 96
-    static constexpr bool TAIL16 = COUT_T % 32 == 16;
+    // COUT_T = 32*MT + 16 + 4: a further 4-row strip on v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 channels x 4 pixels per
+    // instruction, one k each) - 84 landmarks fit exactly instead of padding to 96
+    static constexpr bool TAIL4 = COUT_T % 32 == 20;
+    static constexpr bool TAIL16 = COUT_T % 32 == 16 || TAIL4;
     // the fused argmax serves the last layer only (73 / 84 landmarks -> 80 / 96-row tiles of 8x32 pixels)
     static constexpr bool HAS_AMAX = NIMG == 1 && TW == 32 && TRI == 8 && KS != 1 && (COUT_T == 80 || COUT_T == 96);
     static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
@@ -59,12 +62,13 @@ struct Cfg {
     static constexpr size_t LDS_BYTES = size_t(2 * STAGE + 2 * BN_MAXC) * 4;
     // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
     // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
-    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0);
+    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0) + (TAIL4 ? 4 : 0);
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
     static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
                   "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
+    static_assert(!TAIL4 || PIX_T == 256, "the 4-row strip gives every lane of a wave one pixel: 64 pixels per wave");
     static_assert(COUT_T % 32 == 0 || (TAIL16 && !SPLITK && CK == 4 && TW == 32 && NIMG == 1),
                   "cout tile must be a multiple of the 32-row MFMA tile (+ one 16-row strip on the 32-pixel-row tiles)");
     static_assert(CK % 2 == 0, "the f32 MFMA consumes two k values per step");
@@ -79,6 +83,13 @@ struct StageRegs {
     float xv[C::X_ITERS];
     f32x4 wv[C::W_ITERS];
     float bn_s[C::X_ITERS], bn_t[C::X_ITERS];
+};
+
+// 4-row strip (TAIL4): lane l supplies the weight of channel 32 MT + 16 + (l & 3) (A row of every 4x4 block) and the
+// input of ITS pixel (B column l & 3 of block l >> 2); accumulator register v = channel 32 MT + 16 + v at the lane's pixel
+struct Strip4 {
+    int woff4 = 0, pixoff4 = 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 };
 
 // Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
@@ -143,7 +154,7 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
                                               unsigned HWin, const float* sbn, int woff, const int (&pixoff)[C::NT],
                                               const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
                                               StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT], int woff16,
-                                              const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16]) {
+                                              const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16], Strip4& s4) {
     constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
     // staging schedule of the next chunk: loads issued over the first ISSUE_SPAN k-steps, LDS writes over the last WRITE_SPAN
 #if !defined(MVLM_STAGE_ISSUE_DIV)
@@ -157,6 +168,14 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
     constexpr int WRITE_START = C::KSTEPS - WRITE_SPAN;
     float av[2][C::MT], bv[2][C::NT];
     float a16 = 0.f, b16[C::NT16];  // 16-row strip: operands of one tap's four channels (two k-steps)
+    float a4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, b4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // 4-row strip: [k-step parity][channel of the pair]
+    if constexpr (C::TAIL4) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            a4[0][c] = st[s4.woff4 + c * C::COUT_T];
+            b4[0][c] = st[s4.pixoff4 + c * C::PLANE];
+        }
+    }
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) av[0][m] = st[woff + m * 32];
 #pragma unroll
@@ -171,6 +190,15 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             for (int m = 0; m < C::MT; ++m) av[nx & 1][m] = st[woff + (tap * C::CK + 2 * cp) * C::COUT_T + m * 32];
 #pragma unroll
             for (int n = 0; n < C::NT; ++n) bv[nx & 1][n] = st[2 * cp * C::PLANE + pixoff[n] + toff];
+        }
+        if constexpr (C::TAIL4 && nx < C::KSTEPS) {
+            constexpr int tap4 = nx / (C::CKW / 2), cp4 = nx % (C::CKW / 2);
+            constexpr int toff4 = (tap4 / C::KS) * C::PW + (tap4 % C::KS);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                a4[nx & 1][c] = st[s4.woff4 + (tap4 * C::CK + 2 * cp4 + c) * C::COUT_T];
+                b4[nx & 1][c] = st[s4.pixoff4 + (2 * cp4 + c) * C::PLANE + toff4];
+            }
         }
         if constexpr (C::TAIL16 && (ks & 1) == 0) {
             // the strip's A (16 channels x 4 k) and B (4 k x 16 pixels) fragments of this tap, used
@@ -222,6 +250,11 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             for (int j = 0; j < C::NT16; ++j)
                 acc16[j] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(b16[j], a16, acc16[j], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16[j], acc16[j], 0, 0, 0);
+        }
+        if constexpr (C::TAIL4) {
+            static_assert(!C::TAIL4 || !TR, "the 4-row strip has no transposed (fused-argmax) form");
+#pragma unroll
+            for (int c = 0; c < 2; ++c) s4.acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[ks & 1][c], b4[ks & 1][c], s4.acc, 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         // keep each step's LDS prefetch and side work inside its own MFMA shadow
@@ -338,6 +371,12 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         acc16[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    Strip4 s4;
+    if constexpr (C::TAIL4) {
+        const int p = wave * (C::PIX_T / 4) + lane;  // this lane's pixel of the tile
+        s4.woff4 = C::XT_PAD + C::MT * 32 + 16 + (lane & 3);
+        s4.pixoff4 = (p / C::TW % C::TRI) * C::PW + p % C::TW;
+    }
     // The consumer-side BatchNorm (scale, shift per input channel) is read from an LDS copy.  The first
     // chunk takes its parameters straight from global memory, so the table fill, the first input tile
     // and the first weight slice are ONE memory round trip, closed by the barrier below.
@@ -367,17 +406,17 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     for (int cb = cb0 + C::CK; cb < cb1; cb += C::CK) {
 #if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
         compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
-                                goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+                                goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4);
 #else
         compute_chunk<C, true, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
-                               goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+                               goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4);
 #endif
 #if !defined(MVLM_ABLATE_NO_BARRIER)
         __syncthreads();  // next stage complete; everybody is done reading this one
 #endif
         cur ^= 1;
     }
-    compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16);
+    compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4);
 #if defined(MVLM_CONV_TIMING)
     const long long t_epi = clock64();
 #endif
@@ -863,6 +902,17 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
             }
         }
     }
+    // ---- the 4-row strip: register v = channel co0 + 32 MT + 16 + v at this lane's pixel (64 consecutive pixels per wave)
+    if constexpr (C::TAIL4) {
+        const int p = wave * (C::PIX_T / 4) + lane;
+        const unsigned pix = unsigned(y0 + p / C::TW) * unsigned(W) + unsigned(x0 + p % C::TW);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int co = co0 + C::MT * 32 + 16 + v;
+            if (co < a.cout && a.out)
+                a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix] = s4.acc[v] + (a.bias ? a.bias[co] : 0.f);
+        }
+    }
 
 }
 
@@ -884,6 +934,7 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
     MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
     MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
     MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
+    if (C::TAIL4) MVLM_REQUIRE(ctx, !a.up_out && !a.amax_val && a.out, "conv: the 84-channel tile writes a plain output tensor");
     if (C::TAIL16)
         MVLM_REQUIRE(ctx, !a.res1 && !a.res2 && !a.out_raw && !a.post_scale && a.up_out != 1 && !a.pool_out,
                      "conv: the 80-channel tiles serve plain conv + bias layers only");

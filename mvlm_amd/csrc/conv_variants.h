@@ -42,7 +42,10 @@
     X(23, "conv3x3_sk8_t4x8", Cfg<32, 8, 4, 1, 3, 8, true>) \
     X(24, "conv3x3_sk8_t4x4x2", Cfg<32, 4, 4, 2, 3, 8, true>) \
     X(25, "conv3x3_sk8_t1x32", Cfg<32, 32, 1, 1, 3, 8, true>)
+// 84 output channels (conv6 / conv10 of the 84-landmark network) = 64 + 16 + 4 rows: no padding to 96
+#define MVLM_CONV_VARIANTS_G12(X) \
+    X(26, "conv3x3_c84_t8x32", Cfg<84, 32, 8, 1, 3, 4>)
 #define MVLM_CONV_VARIANTS(X) \
-    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X)
-#define MVLM_CONV_N_GROUPS 12
+    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X)
+#define MVLM_CONV_N_GROUPS 13
 #endif

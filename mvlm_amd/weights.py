@@ -19,6 +19,7 @@ from . import arch
 
 CIN_ALIGN = 4    # smallest K-chunk of the conv kernel (channels per LDS stage)
 COUT_ALIGN = 32  # one MFMA 32x32 tile of output channels
+COUT_EXACT_84 = 84  # conv6 / conv10 of the 84-landmark network run unpadded on the 64 + 16 + 4-row tile
 COUT_TAIL_PADS = (80,)  # plain conv+bias layers may run as 64 rows + one 16-row MFMA strip (73 landmarks -> 80, not 96)
 DESC_INTS = 12   # int32 fields per conv slot in the descriptor table
 
@@ -148,6 +149,8 @@ def pack_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: in
         plain = s.has_bias and s.pre_bn is None and s.post_bn is None  # conv6, conv7, conv10, conv11(+parity)
         if plain and _round_up(s.cout, 16) in COUT_TAIL_PADS:
             cout_pad = _round_up(s.cout, 16)
+        elif plain and s.ksize == 3 and s.cout == COUT_EXACT_84 and s.name in ("conv6", "conv10"):
+            cout_pad = s.cout  # 64 + 16 + 4 rows (conv3x3_c84_t8x32); conv11 keeps 96: its kernels carry the fused argmax
         row[4:6] = (cin_pad, cout_pad)
         if not s.present:
             continue

@@ -38,6 +38,8 @@ CONV_CASES = [
     (73, 73, 64, 3, 2, dict(bias=True, up=True)),                # c80, cin 73 -> 76, upsampled input (conv11 shape)
     (84, 84, 64, 3, 1, dict(bias=True, up=True)),                # cin padding 84 -> 88, upsampled input
     (73, 256, 32, 3, 1, dict(bias=True, res=True)),              # cin 73 -> 80
+    (256, 84, 32, 3, 2, dict(bias=True)),                        # c84: 84 = 64 + a 16-row + a 4-row strip (conv6 / conv10)
+    (40, 84, 64, 3, 1, dict(bias=True)),                         # c84, ten 4-channel chunks, two row tiles per image
     (3, 64, 64, 3, 1, dict(bias=True, post=True)),               # conv1-like
     (64, 128, 32, 1, 2, dict(pre=True)),                         # 1x1 resample
     (256, 128, 16, 3, 3, dict(pre=True, res=True)),              # 16x16 tiles

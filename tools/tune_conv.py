@@ -20,7 +20,7 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))
 
-N_VARIANTS = 26
+N_VARIANTS = 27
 # tiles that fold several images into one MFMA column are only used at the level they were written for
 NATIVE_WIDTH = {"conv3x3_c32_t8x8x2": 8, "conv3x3_c32_t4x4x8": 4, "conv3x3_sk_t4x4x2": 4, "conv3x3_sk16_t4x4x2": 4, "conv3x3_sk8_t4x4x2": 4}
 HEADER = REPO / "mvlm_amd" / "csrc" / "conv_tuned.h"
@@ -105,6 +105,8 @@ def write_header(table, ids):
         cin_pad = (r["cin"] + 7) // 8 * 8 if r["ksize"] == 1 else (r["cin"] + 3) // 4 * 4
         plain = (r["flags"] & 4) and not (r["flags"] & (1 | 2 | 8))
         cout_pad = (r["cout"] + 15) // 16 * 16 if plain and (r["cout"] + 15) // 16 * 16 in weights.COUT_TAIL_PADS else (r["cout"] + 31) // 32 * 32
+        if plain and r["ksize"] == 3 and r["cout"] == weights.COUT_EXACT_84:
+            cout_pad = 84  # conv6 / conv10 (conv11 is not tuned: fixed kernels)
         return cin_pad, cout_pad
 
     rows = {}
