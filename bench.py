@@ -2,7 +2,9 @@
 """Benchmark of the mvlm predict_one_file hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1, either form: `python bench.py --gpus N ...` alone starts its N ranks itself (fresh child processes under
+  torch.distributed.run; the parent never touches the GPU and relays rank 0's JSON line), or an external
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (RANK set) runs as a rank.
 
 A "step" is one pass of the hot path over one mesh: render all views of a ~100k-triangle textured
 face mesh, run the landmark network on every view, take the heatmap maxima, build the rays, fuse
@@ -181,6 +183,57 @@ def committed_traffic(workload_key: str, kernel: str):
     return None, None
 
 
+def visible_gpus() -> int:
+    """GPUs a child rank could open, counted WITHOUT initialising the runtime in this process
+    (torch.cuda.device_count() does not open a device on ROCm builds; the parent of the ranks must not)."""
+    import torch
+
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no RANK in the environment (how the driver starts it): start the N ranks
+    as fresh child processes - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same arguments>` - relay rank 0's ONE JSON line to stdout, the
+    children's stderr to stderr, and return their exit code.  Nothing here makes a HIP call."""
+    import socket
+    import subprocess
+
+    share = os.environ.get("MVLM_BENCH_SHARE_GPU") == "1"
+    have = visible_gpus()
+    if have < n and not share:
+        log(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have} "
+            f"(MVLM_BENCH_SHARE_GPU=1 rehearses the {n}-rank path with every rank on GPU 0 over gloo)")
+        return 2
+    if have < 1:
+        log("bench.py: no GPU visible")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    log("bench.py: starting", " ".join(cmd))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            log(out)  # anything else a rank or the launcher wrote to stdout
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("bench.py: the ranks exited cleanly without a result line")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +255,10 @@ def main():
     ap.add_argument("--cpu-views", type=int, default=-1, help="views in the CPU-baseline sample (-1 = the whole workload, at most 96; 0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as a plain process: the N ranks are this process's children; it never touches the GPU itself
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,6 +266,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if world > 1 and os.environ.get("MVLM_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < world:
+        log(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPUs")
+        sys.exit(2)
     # MVLM_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single GPU (gloo, every rank on
     # device 0); the real run is one rank per GPU over RCCL ("nccl" backend on ROCm)
     share_gpu = os.environ.get("MVLM_BENCH_SHARE_GPU") == "1"

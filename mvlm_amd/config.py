@@ -13,7 +13,7 @@ from pathlib import Path
 
 from . import arch
 
-__all__ = ["MVLMConfig", "load_config", "default_config"]
+__all__ = ["MVLMConfig", "load_config", "default_config", "REFERENCE_CONFIGS"]
 
 
 @dataclass
@@ -32,6 +32,7 @@ class MVLMConfig:
     heatmap_max_quantile: float = 0.5
     heatmap_abs_threshold: float = 0.5
     off_screen_rendering: bool = True
+    write_renderings: bool = False           # process_3d.write_renderings: PNG dump of the rendered views
     angles: dict = field(default_factory=lambda: dict(min_x_angle=-40, max_x_angle=40, min_y_angle=-80,
                                                       max_y_angle=80, min_z_angle=-20, max_z_angle=20))
     pre_align: dict = field(default_factory=lambda: dict(align_center_of_mass=False, rot_x=0, rot_y=0, rot_z=0,
@@ -60,6 +61,10 @@ class MVLMConfig:
 
         self.validate()
         cls = BU3DFEPipeline if self.name == "MVLMModel_BU_3DFE" else DTU3DPipeline
+        if self.write_renderings:
+            kwargs.setdefault("render_image_stack", True)  # general_pipeline.py:133-146, next to the scan unless a folder is given
+        if self.n_gpu > 1:
+            kwargs.setdefault("n_gpus", self.n_gpu)
         pipe = cls(n_views=n_views or self.n_views, image_mode=self.image_channels, **kwargs)
         if pipe.get_lm_count() != self.n_landmarks:
             raise ValueError(f"config asks for {self.n_landmarks} landmarks, {self.name} has {pipe.get_lm_count()}")
@@ -96,6 +101,7 @@ def load_config(src) -> MVLMConfig:
     cfg.heatmap_max_quantile = float(p3.get("heatmap_max_quantile", cfg.heatmap_max_quantile))
     cfg.heatmap_abs_threshold = float(p3.get("heatmap_abs_threshold", cfg.heatmap_abs_threshold))
     cfg.off_screen_rendering = bool(p3.get("off_screen_rendering", cfg.off_screen_rendering))
+    cfg.write_renderings = bool(p3.get("write_renderings", cfg.write_renderings))
     for k in list(cfg.angles):
         if k in p3:
             cfg.angles[k] = p3[k]
@@ -107,21 +113,64 @@ def load_config(src) -> MVLMConfig:
     return cfg
 
 
-def default_config(dataset: str, image_channels: str, n_views: int = 96) -> dict:
-    """A config dict with the reference's schema, e.g. default_config("DTU3D", "RGB")
-    has the inference-relevant content of configs/DTU3D-RGB.json."""
+# What each of the reference's configs/*.json says at inference, as differences from the common block that
+# default_config() writes out (configuration values, checked key by key against the files in
+# tests/test_host_logic.py when /root/reference is present).  n_views 96 and batch_size 8 unless listed.
+REFERENCE_CONFIGS = {
+    "BU_3DFE-RGB+depth": dict(dataset="BU_3DFE", mode="RGB+depth", n_views=8),
+    "BU_3DFE-RGB": dict(dataset="BU_3DFE", mode="RGB", n_views=64, batch_size=4,
+                        pre_align=dict(align_center_of_mass=True, scale=10)),
+    "BU_3DFE-RGB_train_test": dict(dataset="BU_3DFE", mode="RGB",
+                                   process_3d=dict(min_x_angle=-90, max_x_angle=20, min_y_angle=-60, max_y_angle=60,
+                                                   min_z_angle=-40, max_z_angle=40)),
+    "BU_3DFE-depth": dict(dataset="BU_3DFE", mode="depth", pre_align=dict(align_center_of_mass=True, scale=20)),
+    "BU_3DFE-geometry+depth": dict(dataset="BU_3DFE", mode="geometry+depth"),
+    "BU_3DFE-geometry": dict(dataset="BU_3DFE", mode="geometry"),
+    "DTU3D-RGB+depth": dict(dataset="DTU3D", mode="RGB+depth"),
+    "DTU3D-RGB": dict(dataset="DTU3D", mode="RGB"),
+    "DTU3D-RGB_Artec3D": dict(dataset="DTU3D", mode="RGB", process_3d=dict(write_renderings=True),
+                              pre_align=dict(rot_x=-90, write_pre_aligned=True)),
+    "DTU3D-RGB_BU3DFE_RAW": dict(dataset="DTU3D", mode="RGB", pre_align=dict(rot_x=-35)),
+    "DTU3D-RGB_infinite": dict(dataset="DTU3D", mode="RGB", process_3d=dict(write_renderings=True),
+                               pre_align=dict(scale=800, write_pre_aligned=True)),
+    "DTU3D-depth-MRI": dict(dataset="DTU3D", mode="depth", process_3d=dict(write_renderings=True),
+                            pre_align=dict(align_center_of_mass=True, rot_z=180, write_pre_aligned=True)),
+    "DTU3D-depth": dict(dataset="DTU3D", mode="depth"),
+    "DTU3D-depth_infinite": dict(dataset="DTU3D", mode="depth", process_3d=dict(write_renderings=True),
+                                 pre_align=dict(scale=800, write_pre_aligned=True)),
+    "DTU3D-geometry+depth": dict(dataset="DTU3D", mode="geometry+depth"),
+    "DTU3D-geometry+depth_BU3DFE_RAW": dict(dataset="DTU3D", mode="geometry+depth", pre_align=dict(rot_x=-35)),
+    "DTU3D-geometry": dict(dataset="DTU3D", mode="geometry"),
+}
+
+
+def default_config(dataset: str, image_channels: str | None = None, n_views: int | None = None) -> dict:
+    """A config dict with the reference's schema and the inference-relevant content of the file of that name:
+    ``default_config("BU_3DFE", "depth")`` == ``default_config("BU_3DFE-depth")`` has what configs/BU_3DFE-depth.json
+    has (pre-align: centre of mass + scale 20, 96 views); any of the 17 file stems is accepted as the first argument.
+    ``n_views`` overrides the file's view count (BASELINE.json quotes its configurations at view counts of its own)."""
+    stem = dataset if image_channels is None else f"{dataset}-{image_channels}"
+    if stem not in REFERENCE_CONFIGS:
+        raise ValueError(f"no reference config named {stem}.json; known: {sorted(REFERENCE_CONFIGS)}")
+    spec = REFERENCE_CONFIGS[stem]
+    dataset, image_channels = spec["dataset"], spec["mode"]
     name = {"DTU3D": "MVLMModel_DTU3D", "BU_3DFE": "MVLMModel_BU_3DFE"}[dataset]
+    process_3d = {"filter_view_lines": "quantile", "heatmap_max_quantile": 0.5, "heatmap_abs_threshold": 0.5,
+                  "write_renderings": False, "off_screen_rendering": True, "min_x_angle": -40, "max_x_angle": 40,
+                  "min_y_angle": -80, "max_y_angle": 80, "min_z_angle": -20, "max_z_angle": 20}
+    process_3d.update(spec.get("process_3d", {}))
+    pre_align = {"align_center_of_mass": False, "rot_x": 0, "rot_y": 0, "rot_z": 0, "scale": 1,
+                 "write_pre_aligned": False}
+    pre_align.update(spec.get("pre_align", {}))
     return {
         "name": name,
         "n_gpu": 1,
         "arch": {"type": "MVLMModel", "args": {"n_landmarks": 73 if dataset == "DTU3D" else 84, "n_features": 256,
                                                 "dropout_rate": 0.2, "image_channels": image_channels}},
         "data_loader": {"type": "FaceDataLoader", "args": {"heatmap_size": 256, "image_size": 256,
-                                                           "image_channels": image_channels, "n_views": n_views,
-                                                           "batch_size": 8}},
-        "process_3d": {"filter_view_lines": "quantile", "heatmap_max_quantile": 0.5, "heatmap_abs_threshold": 0.5,
-                       "off_screen_rendering": True, "min_x_angle": -40, "max_x_angle": 40, "min_y_angle": -80,
-                       "max_y_angle": 80, "min_z_angle": -20, "max_z_angle": 20},
-        "pre-align": {"align_center_of_mass": False, "rot_x": 0, "rot_y": 0, "rot_z": 0, "scale": 1,
-                      "write_pre_aligned": False},
+                                                           "image_channels": image_channels,
+                                                           "n_views": int(n_views or spec.get("n_views", 96)),
+                                                           "batch_size": spec.get("batch_size", 8)}},
+        "process_3d": process_3d,
+        "pre-align": pre_align,
     }

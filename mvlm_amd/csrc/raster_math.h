@@ -1,5 +1,6 @@
-// Scalar arithmetic of the multi-view rasteriser, written once so the HIP kernels
-// (raster.hip) and their tests agree bit for bit on every pixel.  Plain C99 subset.
+// Scalar arithmetic of the multi-view rasteriser, written once for all kernels of raster.hip
+// (transform, classify, tile) so they agree bit for bit on every pixel.  Plain C99 subset.
+// The tests do NOT share this file: their checker, oracle/raster.c, is an independent restatement.
 //
 // What it restates (reference: src/mvlm/utils/render3d.py, all of it executed inside
 // the third-party VTK/OpenGL stack there):

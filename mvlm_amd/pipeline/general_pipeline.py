@@ -15,7 +15,9 @@ is driven through the reference's numpy slot protocol instead.
 from __future__ import annotations
 
 import abc
+import functools
 import os
+import threading
 import time
 from pathlib import Path
 
@@ -28,6 +30,18 @@ from ..utils.hostmem import retain_freed_host_memory
 from ..utils.render3d import HipRenderer3D
 
 __all__ = ["Pipeline"]
+
+
+def _serialised(method):
+    """One caller at a time per pipeline.  The reference's server calls ``predict_one_file`` from a thread pool
+    without locks (3DMD_server.py:26-31); here a call owns the pipeline's device buffers (image stack, maxima,
+    result pack), its captured launch graphs, ``timings`` and the per-call ray state, so the whole call - RNG
+    draws included - runs under the pipeline's re-entrant lock."""
+    @functools.wraps(method)
+    def locked(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    return locked
 
 
 def _drop(box: list) -> None:
@@ -89,9 +103,9 @@ class Pipeline(abc.ABC):
         self.last_error: float | None = None
         self._rays = None  # (mesh, starts, ends) of the current call when visualize_rays is set
         self._buffers: dict = {}
-        # optional "pre-align" block of a Deep-MVLM config (mvlm_amd/utils/prealign.py); the
-        # reference's live pipeline has none (it renders the mesh as-is)
-        self.pre_align: dict | None = None
+        self._lock = threading.RLock()  # see _serialised
+        self._pre_align: dict | None = None
+        self.write_pre_aligned_folder: Path | None = None
 
         retain_freed_host_memory()  # scans come and go: keep their host pages (utils/hostmem.py; MVLM_HOST_MALLOC_TUNING=0 opts out)
         if shard_views:
@@ -104,6 +118,32 @@ class Pipeline(abc.ABC):
                                          verbose=verbose)
         self.estimator_3d = HipEstimator3D(device=device, verbose=verbose)
         self.predictor_2d = None  # will be assigned externally
+
+    @property
+    def pre_align(self) -> dict | None:
+        """Optional "pre-align" block of a Deep-MVLM config (mvlm_amd/utils/prealign.py, utils3d.py:465-527); the
+        reference's live pipeline has none (it renders the mesh as-is).  It lives on the renderer slot, which is
+        the object that loads meshes; both the fused path and the slot protocol honour it."""
+        return getattr(self.renderer_3d, "pre_align", self._pre_align)
+
+    @pre_align.setter
+    def pre_align(self, block: dict | None) -> None:
+        from ..utils.prealign import is_active
+
+        self._pre_align = block
+        if hasattr(self.renderer_3d, "pre_align"):
+            self.renderer_3d.pre_align = block
+        elif is_active(block):
+            raise ValueError("a pre-align block needs a renderer that applies it (HipRenderer3D.pre_align)")
+
+    def _to_original(self, mesh, landmarks):
+        """Landmarks found on a pre-aligned mesh -> the file's own coordinates (utils3d.py:505-527)."""
+        m = getattr(mesh, "to_original", None)
+        if m is None or landmarks is None:
+            return landmarks
+        from ..utils.prealign import landmarks_to_original_space
+
+        return landmarks_to_original_space(landmarks, m)
 
     def get_lm_count(self) -> int:
         if self.predictor_2d is None:
@@ -142,6 +182,7 @@ class Pipeline(abc.ABC):
         return (isinstance(self.renderer_3d, HipRenderer3D) and isinstance(self.estimator_3d, HipEstimator3D)
                 and device_predictor)
 
+    @_serialised
     def predict_one_file(self, file_name: Path, landmark_indices: list[int] | None = None,
                          view_indices: list[int] | None = None, clip_rays_to_mesh: bool = True):
         if self.predictor_2d is None:
@@ -191,6 +232,7 @@ class Pipeline(abc.ABC):
         return out
 
     # ---- fused device-resident path ----------------------------------------------------
+    @_serialised
     def predict_mesh_device(self, mesh, transform_stack):
         """Render + network + fusion + snap for an already loaded mesh and pose table.
         Returns (landmarks [NL,3] float64 numpy, mean RANSAC error).  With
@@ -292,11 +334,12 @@ class Pipeline(abc.ABC):
         p2, e3 = self.predictor_2d, self.estimator_3d
         if n_scans < 2 or not self._fusable() or not isinstance(p2, HipPaulsenModel):
             return False
-        if (self.shard_views and parallel.is_distributed()) or self.render_image_stack or self.visualize_rays or self.pre_align:
+        if (self.shard_views and parallel.is_distributed()) or self.render_image_stack or self.visualize_rays:
             return False
         n = int(self.renderer_3d.n_views)
         return e3.expected_counts(p2.get_lm_count(), n) is not None and n_scans * n <= (p2.device_batch or 128)
 
+    @_serialised
     def predict_meshes_device(self, meshes, pose_fn=None):
         """Several loaded scans through ONE pass of the network: with few views per scan (the reference's default 8) a
         pass over 8 views runs the matrix cores at 0.64 of what a pass over 64 does.  Every scan is rendered into its
@@ -313,8 +356,15 @@ class Pipeline(abc.ABC):
         r3, p2, e3 = self.renderer_3d, self.predictor_2d, self.estimator_3d
         pose_fn = pose_fn or r3.generate_3d_transformations
         k = len(meshes)
+        from ..utils.prealign import aligned
+
+        meshes = [aligned(m, self.pre_align) for m in meshes]
         if not self._groupable(k):
-            return [self.predict_mesh_device(m, pose_fn()) for m in meshes]
+            out = []
+            for m in meshes:
+                landmarks, err = self.predict_mesh_device(m, pose_fn())
+                out.append((self._to_original(m, landmarks), err))
+            return out
         nl, n = p2.get_lm_count(), int(r3.n_views)
         per = (nl * 36 + 7) // 8 * 8
         stacks, rots, rot_devs, plans = [], [], [], []
@@ -354,6 +404,9 @@ class Pipeline(abc.ABC):
             landmarks = host_seg[: nl * 24].view(np.float64).reshape(nl, 3).copy()
             return landmarks, e3.mean_error(host_seg[nl * 24: nl * 32].view(np.float64))
 
+        def original(j, res):
+            return self._to_original(meshes[j], res[0]), res[1]
+
         with tm.stage("project"):
             host = pack[: k * per].cpu().numpy()
             for j in range(k):
@@ -363,11 +416,11 @@ class Pipeline(abc.ABC):
                     # other survivor counts than planned: this scan's draws + solve were repeated from its saved RNG
                     # state; the RNG now stands where the loop would have it, so the remaining scans go one by one
                     e3.project_device(meshes[j], out, out=snap_view)
-                    results.append(unpack(pack[j * per:(j + 1) * per].cpu().numpy()))
+                    results.append(original(j, unpack(pack[j * per:(j + 1) * per].cpu().numpy())))
                     for i in range(j + 1, k):
-                        results.append(self.predict_mesh_device(meshes[i], pose_fn()))
+                        results.append(original(i, self.predict_mesh_device(meshes[i], pose_fn())))
                     break
-                results.append(unpack(seg))
+                results.append(original(j, unpack(seg)))
             r3.check()
         self.last_error = results[-1][1]
         return results
@@ -401,7 +454,7 @@ class Pipeline(abc.ABC):
         def ingest(f: Path):
             if not f.exists():
                 return None
-            mesh = load_obj(self.renderer_3d._check_file(f))
+            mesh = self.renderer_3d.load_mesh(self.renderer_3d._check_file(f))  # pre-aligned here, uploaded once
             if mesh.n_tris > 0:
                 # device copy from the reader thread too: pinned staging + a copy stream of the library's own, so the
                 # transfer runs beside the current scan's kernels (mvlm_mesh_upload); the renderer waits for its event
@@ -422,19 +475,27 @@ class Pipeline(abc.ABC):
             def flush():
                 if not group:
                     return
-                with self._timer.stage("total"):
-                    results = self.predict_meshes_device([m for _, m in group])
-                for (gf, gm), (landmarks, _) in zip(group, results):
-                    self._rays = None
-                    self._after_prediction(gf, landmarks)
-                    yield gf, landmarks
+                with self._lock:  # held for the group's GPU section only, never across a yield
+                    with self._timer.stage("total"):
+                        results = self.predict_meshes_device([m for _, m in group])
+                    for (gf, gm), (landmarks, _) in zip(group, results):
+                        self._rays = None
+                        self._after_prediction(gf, landmarks)
+                done = [(gf, landmarks) for (gf, _), (landmarks, _) in zip(group, results)]
                 pool.submit(_drop, [m for _, m in group])
                 group.clear()
+                yield from done
 
             for i, f in enumerate(files):
                 if i + prefetch < len(files):
                     pending.append(pool.submit(ingest, files[i + prefetch]))
-                mesh = pending.pop(0).result()  # re-raises the reader's ValueError / FileNotFoundError
+                try:
+                    mesh = pending.pop(0).result()  # re-raises the reader's ValueError / FileNotFoundError
+                except BaseException:
+                    # the one-by-one loop would have delivered every scan before the malformed one: the scans
+                    # waiting in the group get their results first, then the error goes to the caller
+                    yield from flush()
+                    raise
                 if mesh is None:
                     yield from flush()
                     print(f"File {f} does not exist")
@@ -446,10 +507,11 @@ class Pipeline(abc.ABC):
                     if len(group) == batch_scans or i + 1 == len(files):
                         yield from flush()
                     continue
-                self._rays = None
-                with self._timer.stage("total"):
-                    landmarks = self._predict_fused(f, mesh=mesh)
-                self._after_prediction(f, landmarks)
+                with self._lock:
+                    self._rays = None
+                    with self._timer.stage("total"):
+                        landmarks = self._predict_fused(f, mesh=mesh)
+                    self._after_prediction(f, landmarks)
                 # returning a scan's 10-25 MB of host arrays to the OS costs milliseconds (page
                 # unmapping under the GPU driver's MMU notifier): let the reader thread drop them
                 # while this thread goes on to the next scan
@@ -459,12 +521,14 @@ class Pipeline(abc.ABC):
             yield from flush()
 
     def _predict_fused(self, file_name: Path, mesh=None):
-        from ..utils.mesh_io import load_obj
+        from ..utils.prealign import aligned
 
         t0 = time.perf_counter()
         if mesh is None:
             file_name = self.renderer_3d._check_file(file_name)
-            mesh = load_obj(file_name)
+            mesh = self.renderer_3d.load_mesh(file_name)
+        else:
+            mesh = aligned(mesh, self.pre_align)
         sharded = self.shard_views and parallel.is_distributed()
         if sharded:
             rank, _ = parallel.rank_world()
@@ -473,18 +537,19 @@ class Pipeline(abc.ABC):
         else:
             poses = self.renderer_3d.generate_3d_transformations()
         self.timings["load"] = time.perf_counter() - t0
-        matrix = None
-        if self.pre_align and any(self.pre_align.get(k) for k in ("align_center_of_mass", "rot_x", "rot_y", "rot_z")) \
-                or (self.pre_align and float(self.pre_align.get("scale", 1)) != 1.0):
-            from ..utils.prealign import apply_prealign
-
-            mesh, matrix = apply_prealign(mesh, self.pre_align)
+        self._dump_pre_aligned(mesh, file_name)
         landmarks, _ = self.predict_mesh_device(mesh, poses)
-        if matrix is not None:
-            from ..utils.prealign import landmarks_to_original_space
+        return self._to_original(mesh, landmarks)
 
-            landmarks = landmarks_to_original_space(landmarks, matrix)
-        return landmarks
+    def _dump_pre_aligned(self, mesh, file_name):
+        """``pre-align.write_pre_aligned`` (utils3d.py:489-494): the transformed surface as a legacy .vtk file."""
+        block = self.pre_align
+        if not (block and block.get("write_pre_aligned") and getattr(mesh, "to_original", None) is not None):
+            return
+        from ..utils.prealign import write_pre_aligned
+
+        folder = Path(self.write_pre_aligned_folder) if self.write_pre_aligned_folder else Path(file_name).parent
+        write_pre_aligned(mesh, folder / f"{Path(file_name).stem}_pre_transform_mesh.vtk")
 
     # ---- the reference's numpy slot protocol (general_pipeline.py:83-108) ----------------
     def _predict_slots(self, file_name: Path):
@@ -508,7 +573,10 @@ class Pipeline(abc.ABC):
             landmarks = self.estimator_3d.project_landmarks_to_surface(pd, landmarks)
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error
-        return landmarks
+        self._dump_pre_aligned(pd, file_name)
+        # a mesh handle that went through the config's pre-align block carries its matrix: results go back to
+        # the file's coordinates (the rays kept for visualisation stay in the aligned space, with the mesh handle)
+        return self._to_original(pd, landmarks)
 
     def visualize_image_stack(self, image_stack: np.ndarray, file_name: Path, first_index: int = 0):
         """PNG dump of the rendered views (general_pipeline.py:133-146)."""

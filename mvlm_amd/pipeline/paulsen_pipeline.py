@@ -6,7 +6,7 @@ from .general_pipeline import Pipeline
 
 __all__ = ["BU3DFEPipeline", "DTU3DPipeline"]
 
-_PREDICTOR_KEYS = ("weights", "image_mode", "selection_method", "batch_size", "device_batch", "model_dir", "precision")
+_PREDICTOR_KEYS = ("weights", "image_mode", "selection_method", "batch_size", "device_batch", "model_dir", "precision", "n_gpus")
 
 
 def _split(kwargs):

@@ -78,9 +78,39 @@ class HipPaulsenModel(Predictor2D):
             self.ctx.handle, _lib.as_ptr(blob, C.c_float), blob.size, _lib.as_ptr(desc, C.c_int32), desc.shape[0],
             self.get_lm_count(), self.in_channels))
         self._state_dict, self._desc = state_dict, desc
+        # n_gpus > 1: the reference's single-process form (paulsenpredictor.py:100-105, nn.DataParallel over
+        # device_ids): one replica of the weights per further device, the views of a call split contiguously over
+        # the devices, the maxima gathered on this model's own device
+        self._replicas: list[_Replica] = []
+        for d in self._replica_devices(n_gpus, device):
+            rctx = _lib.Context(d)
+            rctx.check(rctx.lib.mvlm_cnn_load(
+                rctx.handle, _lib.as_ptr(blob, C.c_float), blob.size, _lib.as_ptr(desc, C.c_int32), desc.shape[0],
+                self.get_lm_count(), self.in_channels))
+            self._replicas.append(_Replica(rctx))
         self._fast_loaded = False
         self.precision = "exact"
         self.set_precision(precision)
+
+    @staticmethod
+    def _replica_devices(n_gpus, device: int) -> list[int]:
+        """Device indices of the replicas beside ``device``.  Like ``_prepare_device`` (paulsenpredictor.py:72-87) a
+        request for more GPUs than the machine has is clamped - with a message instead of silently.
+        MVLM_REPLICA_DEVICES="0,0" names the devices explicitly (rehearsal of the N-device path on one GPU)."""
+        import torch
+
+        forced = os.environ.get("MVLM_REPLICA_DEVICES")
+        if forced:
+            ids = [int(v) for v in forced.split(",") if v.strip() != ""]
+            return ids[1:]
+        n_gpus = int(n_gpus or 1)
+        if n_gpus <= 1:
+            return []
+        have = torch.cuda.device_count()
+        if n_gpus > have:
+            print(f"Warning: n_gpus={n_gpus} requested, {have} GPU(s) visible - using {have}")
+            n_gpus = have
+        return [d for d in range(have) if d != device][: max(0, n_gpus - 1)]
 
     def set_precision(self, precision: str):
         """"exact" (default): every convolution in exact fp32 on the matrix cores - the path all parity claims are
@@ -93,8 +123,13 @@ class HipPaulsenModel(Predictor2D):
             self.ctx.check(self.ctx.lib.mvlm_cnn_load_fast(
                 self.ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
                 offsets.ctypes.data_as(C.POINTER(C.c_int64)), offsets.shape[0]))
+            for r in self._replicas:
+                r.ctx.check(r.ctx.lib.mvlm_cnn_load_fast(
+                    r.ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
+                    offsets.ctypes.data_as(C.POINTER(C.c_int64)), offsets.shape[0]))
             self._fast_loaded = True
-        self.ctx.check(self.ctx.lib.mvlm_cnn_set_precision(self.ctx.handle, 1 if precision == "fast" else 0))
+        for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
+            ctx.check(ctx.lib.mvlm_cnn_set_precision(ctx.handle, 1 if precision == "fast" else 0))
         self.precision = precision
 
     @abc.abstractmethod
@@ -134,21 +169,52 @@ class HipPaulsenModel(Predictor2D):
     def _batch_for(self, n_views: int) -> int:
         return max(1, min(n_views, self.device_batch or 128))
 
-    def _get_workspace(self, batch: int):
+    def _get_workspace(self, batch: int, holder=None):
         import torch
 
-        need = int(self.ctx.lib.mvlm_cnn_workspace_bytes(self.ctx.handle, batch))
+        holder = holder or self
+        ctx = holder.ctx
+        need = int(ctx.lib.mvlm_cnn_workspace_bytes(ctx.handle, batch))
         if need == 0:
             raise _lib.MvlmHipError("mvlm_cnn_workspace_bytes returned 0 (weights not loaded?)")
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = None
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", self.ctx.device))
-        return self._workspace
+        if holder._workspace is None or holder._workspace.numel() < need:
+            holder._workspace = None
+            holder._workspace = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", ctx.device))
+        return holder._workspace
+
+    def _maxima_on(self, holder, x, maxima):
+        """The network + maxima of the views ``x`` (on ``holder``'s device) into ``maxima`` [NL,n,3] there."""
+        import torch
+
+        ctx = holder.ctx
+        dev = torch.device("cuda", ctx.device)
+        n, nl = int(x.shape[0]), self.get_lm_count()
+        batch = self._batch_for(n)
+        ws = self._get_workspace(batch, holder)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        if self.selection_method == "simple":
+            ctx.check(ctx.lib.mvlm_cnn_maxima(
+                ctx.handle, C.c_void_p(x.data_ptr()), n, _lib.as_ptr(self.chan_sel, C.c_int32),
+                C.c_void_p(maxima.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
+            return
+        for s in range(0, n, batch):  # "moment" needs the heatmap neighbourhood of each peak (:129-156)
+            nb = min(batch, n - s)
+            heat = torch.empty((nb, nl, 256, 256), dtype=torch.float32, device=dev)
+            part = torch.empty((nl, nb, 3), dtype=torch.float32, device=dev)
+            ctx.check(ctx.lib.mvlm_cnn_heatmaps(
+                ctx.handle, C.c_void_p(x[s:s + nb].data_ptr()), nb, _lib.as_ptr(self.chan_sel, C.c_int32),
+                C.c_void_p(heat.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
+            ctx.check(ctx.lib.mvlm_heatmap_maxima(ctx.handle, C.c_void_p(heat.data_ptr()), nb, nl, 256,
+                                                  1, C.c_void_p(part.data_ptr())))
+            maxima[:, s:s + nb] = part
 
     def predict_device(self, image_stack_dev, out=None):
         """torch f32 [N,256,256,4] on this GPU -> maxima torch f32 [NL,N,3] on the GPU (written into ``out``
         when given).  A pass over the same buffers is captured as a hipGraph on its second use and replayed
-        afterwards (mvlm_cnn_set_execution), so callers in a loop should hand over stable buffers."""
+        afterwards (mvlm_cnn_set_execution), so callers in a loop should hand over stable buffers.
+        With ``n_gpus`` > 1 the views are split contiguously over the replicas' devices (the scatter / gather of
+        nn.DataParallel, paulsenpredictor.py:104-105): slices travel device to device, every device's pass is
+        enqueued before any result is fetched, and the maxima come back into ``out`` in view order."""
         import torch
 
         dev = torch.device("cuda", self.ctx.device)
@@ -157,36 +223,58 @@ class HipPaulsenModel(Predictor2D):
         x = image_stack_dev.contiguous()
         n = int(x.shape[0])
         nl = self.get_lm_count()
-        batch = self._batch_for(n)
-        ws = self._get_workspace(batch)
-        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         if out is None:
             maxima = torch.empty((nl, n, 3), dtype=torch.float32, device=dev)
         else:
             maxima = out
             if tuple(out.shape) != (nl, n, 3) or out.dtype != torch.float32 or not out.is_contiguous():
                 raise ValueError("predict_device: out must be a contiguous float32 [NL,N,3] tensor")
-        if self.selection_method == "simple":
-            self.ctx.check(self.ctx.lib.mvlm_cnn_maxima(
-                self.ctx.handle, C.c_void_p(x.data_ptr()), n, _lib.as_ptr(self.chan_sel, C.c_int32),
-                C.c_void_p(maxima.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
-        else:  # "moment" needs the heatmap neighbourhood of each peak (:129-156)
-            for s in range(0, n, batch):
-                nb = min(batch, n - s)
-                heat = torch.empty((nb, nl, 256, 256), dtype=torch.float32, device=dev)
-                part = torch.empty((nl, nb, 3), dtype=torch.float32, device=dev)
-                self.ctx.check(self.ctx.lib.mvlm_cnn_heatmaps(
-                    self.ctx.handle, C.c_void_p(x[s:s + nb].data_ptr()), nb, _lib.as_ptr(self.chan_sel, C.c_int32),
-                    C.c_void_p(heat.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
-                self.ctx.check(self.ctx.lib.mvlm_heatmap_maxima(self.ctx.handle, C.c_void_p(heat.data_ptr()), nb, nl, 256,
-                                                                1, C.c_void_p(part.data_ptr())))
-                maxima[:, s:s + nb] = part
+        if not self._replicas or n < 2:
+            self._maxima_on(self, x, maxima)
+            return maxima
+        from ..parallel import shard_range
+
+        holders = [self] + self._replicas
+        world = len(holders)
+        parts = []
+        # the scatter copies run on THIS device's stream (torch issues a device-to-device copy on the source's
+        # stream), so every replica gets its slice and its pass before this device's own pass is enqueued
+        for r in list(range(1, world)) + [0]:
+            h = holders[r]
+            lo, hi = shard_range(n, r, world)
+            if hi == lo:
+                continue
+            rdev = torch.device("cuda", h.ctx.device)
+            if r == 0:
+                xin = x[lo:hi]
+            else:
+                xin = self._slice_buffer(h, "images", (hi - lo, 256, 256, 4))
+                xin.copy_(x[lo:hi], non_blocking=True)   # device to device (xGMI), ordered by torch's stream events
+            with torch.cuda.device(rdev):
+                # [NL,N,3] is landmark-major: every device computes its [NL,n_r,3] slice into a buffer of its own
+                rmax = self._slice_buffer(h, "maxima", (nl, hi - lo, 3))
+                self._maxima_on(h, xin, rmax)
+            parts.append((lo, hi, rmax))
+        for lo, hi, part in parts:                        # gather: [NL, n_r, 3] slices into view order
+            maxima[:, lo:hi].copy_(part, non_blocking=True)
         return maxima
+
+    @staticmethod
+    def _slice_buffer(holder, name: str, shape: tuple):
+        """A float32 tensor on ``holder``'s device kept from call to call (stable addresses: graph replay)."""
+        import torch
+
+        bufs = holder.__dict__.setdefault("_slice_buffers", {})
+        buf = bufs.get(name)
+        if buf is None or tuple(buf.shape) != tuple(shape):
+            buf = bufs[name] = torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", holder.ctx.device))
+        return buf
 
     def set_execution(self, graphs: bool = True, concurrency: bool = False):
         """How the forward pass is issued (mvlm_cnn_set_execution): replayed hipGraphs / launch by launch, and
         whether small batches run the lower hourglass pyramid on a second stream.  Results do not depend on it."""
-        self.ctx.check(self.ctx.lib.mvlm_cnn_set_execution(self.ctx.handle, int(bool(graphs)), int(bool(concurrency))))
+        for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
+            ctx.check(ctx.lib.mvlm_cnn_set_execution(ctx.handle, int(bool(graphs)), int(bool(concurrency))))
 
     def execution_stats(self) -> dict:
         v = [C.c_int64() for _ in range(4)]
@@ -217,6 +305,14 @@ class HipPaulsenModel(Predictor2D):
         x = torch.from_numpy(np.ascontiguousarray(image_stack, dtype=np.float32)).to(torch.device("cuda", self.ctx.device))
         lms = self.predict_device(x).cpu().numpy()
         return lms, valid
+
+
+class _Replica:
+    """Weights of the model on one further device (``n_gpus`` > 1): its context, workspace and slice buffers."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._workspace = None
 
 
 class BU3DFEPredictor(HipPaulsenModel):

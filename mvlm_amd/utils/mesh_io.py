@@ -30,6 +30,9 @@ class Mesh:
     texture: np.ndarray | None = None  # [H,W,3] uint8, row 0 = top of the image
     path: Path | None = None
     _device: dict = field(default_factory=dict, repr=False)
+    # 4x4 matrix of the config's "pre-align" block this mesh has been through (utils/prealign.py); landmarks found on
+    # it go back to the file's own coordinates through the inverse (utils3d.py:505-527)
+    to_original: np.ndarray | None = None
 
     @property
     def n_verts(self) -> int:

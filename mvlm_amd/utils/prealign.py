@@ -13,7 +13,7 @@ import numpy as np
 
 from .mesh_io import Mesh
 
-__all__ = ["prealign_matrix", "apply_prealign", "landmarks_to_original_space"]
+__all__ = ["prealign_matrix", "apply_prealign", "landmarks_to_original_space", "is_active", "aligned", "write_pre_aligned"]
 
 
 def prealign_matrix(verts: np.ndarray, cfg: dict) -> np.ndarray:
@@ -33,11 +33,38 @@ def prealign_matrix(verts: np.ndarray, cfg: dict) -> np.ndarray:
     return m
 
 
+def is_active(cfg: dict | None) -> bool:
+    """Does the block change the mesh at all?  (every reference config carries one; most are neutral)"""
+    if not cfg:
+        return False
+    return bool(cfg.get("align_center_of_mass", False)) or any(float(cfg.get(k, 0)) != 0.0 for k in ("rot_x", "rot_y", "rot_z")) \
+        or float(cfg.get("scale", 1)) != 1.0
+
+
 def apply_prealign(mesh: Mesh, cfg: dict) -> tuple[Mesh, np.ndarray]:
-    """Transformed copy of the mesh (float32 points like vtkTransformPolyDataFilter) + the matrix."""
+    """Transformed copy of the mesh (float32 points like vtkTransformPolyDataFilter) + the matrix.
+    The copy remembers the matrix (``Mesh.to_original``) so whoever ends up with the landmarks can map them back."""
     m = prealign_matrix(mesh.verts, cfg)
     v = mesh.verts.astype(np.float64) @ m[:3, :3].T + m[:3, 3]
-    return Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, mesh.texture, mesh.path), m
+    return Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, mesh.texture, mesh.path, to_original=m), m
+
+
+def aligned(mesh: Mesh, cfg: dict | None) -> Mesh:
+    """``mesh`` itself when the block is neutral or the mesh has been through it already, else the transformed copy."""
+    if not is_active(cfg) or mesh.to_original is not None:
+        return mesh
+    return apply_prealign(mesh, cfg)[0]
+
+
+def write_pre_aligned(mesh: Mesh, path) -> None:
+    """``write_pre_aligned`` (utils3d.py:489-494 writes the transformed surface as a legacy .vtk): the same file kind,
+    ASCII POLYDATA with the points and triangles of the aligned mesh."""
+    with open(path, "w") as f:
+        f.write("# vtk DataFile Version 3.0\npre-aligned mesh\nASCII\nDATASET POLYDATA\n")
+        f.write(f"POINTS {mesh.n_verts} float\n")
+        np.savetxt(f, mesh.verts, fmt="%.9g")
+        f.write(f"POLYGONS {mesh.n_tris} {4 * mesh.n_tris}\n")
+        np.savetxt(f, np.concatenate([np.full((mesh.n_tris, 1), 3, np.int64), mesh.tris.astype(np.int64)], axis=1), fmt="%d")
 
 
 def landmarks_to_original_space(landmarks: np.ndarray, m: np.ndarray) -> np.ndarray:

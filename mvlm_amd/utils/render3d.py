@@ -111,6 +111,9 @@ class HipRenderer3D:
             raise ValueError("shading must be 'texture' (the reference's unlit render) or 'geometry'")
         # "geometry": build-defined shaded plane for models trained on geometry renderings
         self.shading = shading
+        # "pre-align" block of a Deep-MVLM config (utils/prealign.py; utils3d.py:465-503): applied to every mesh this
+        # renderer loads, the mesh handle it returns carries the matrix (Mesh.to_original)
+        self.pre_align: dict | None = None
         self.ctx = _lib.get_context(device)
 
     # ---- pose table (render3d.py:79-112) ----------------------------------------------
@@ -186,14 +189,20 @@ class HipRenderer3D:
         if self.verbose:
             print("Render [0] - Prepare", f"{time.time() - t:08.6f} s")
         transformation_stack = self.generate_3d_transformations()
-        mesh = load_obj(file_name)
+        mesh = self.load_mesh(file_name)
         image_stack = self.render_device(mesh, transformation_stack).cpu().numpy()
         self.check()
         return image_stack, transformation_stack, mesh
 
+    def load_mesh(self, file_name: Path) -> Mesh:
+        """OBJ (+ texture) from disk, through the ``pre_align`` block when one is set."""
+        from .prealign import aligned
+
+        return aligned(load_obj(file_name), self.pre_align)
+
     def multiview_render_device(self, file_or_mesh, transformation_stack=None):
         """Same, but the image stack stays in HBM (used by the fused pipeline path)."""
-        mesh = file_or_mesh if isinstance(file_or_mesh, Mesh) else load_obj(self._check_file(file_or_mesh))
+        mesh = file_or_mesh if isinstance(file_or_mesh, Mesh) else self.load_mesh(self._check_file(file_or_mesh))
         if transformation_stack is None:
             transformation_stack = self.generate_3d_transformations()
         return self.render_device(mesh, transformation_stack), transformation_stack, mesh

@@ -45,3 +45,16 @@ def write_face_like_obj(path, grid: int = 224, tex_size: int = 512, seed: int = 
     m = face_like_mesh(grid, tex_size, seed)
     write_obj(path, m.verts, m.tris, m.uvs, m.texture)
     return path
+
+
+def unaligned_copy(mesh: Mesh, pre_align: dict, offset=(3.0, -2.0, 1.5)) -> Mesh:
+    """The "raw scan" a config's ``pre-align`` block is written for: a copy of ``mesh`` in the coordinates from which
+    that block (utils/prealign.py) brings it back into the renderer's view box - shrunk by the block's scale, turned
+    by its inverse rotation and, when the block centres the scan, moved off the origin by ``offset``."""
+    from .prealign import prealign_matrix
+
+    m = prealign_matrix(np.zeros((1, 3)), dict(pre_align, align_center_of_mass=False))
+    v = mesh.verts.astype(np.float64) @ np.linalg.inv(m[:3, :3]).T
+    if pre_align.get("align_center_of_mass", False):
+        v = v + np.asarray(offset, dtype=np.float64)
+    return Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, mesh.texture, None)

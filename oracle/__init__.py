@@ -16,4 +16,7 @@ Pinning status (see DESIGN.md "Oracle"):
     in the un-vendored third-party ``vtk`` package, absent here -> PARITY
     UNPINNED at pixel level; pinned only by convention round-trips and analytic
     cases.
+  * prealign (vtkTransform / vtkCenterOfMass of the legacy Utils3D): same
+    absent package -> PARITY UNPINNED at the bit level; the homogeneous-matrix
+    form of the reference's call sequence.
 """

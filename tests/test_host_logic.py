@@ -160,14 +160,63 @@ def test_config_parser(tmp_path, dataset, mode, nl, c):
 
 
 def test_config_parser_reads_reference_files_when_present():
+    """Every configs/*.json of the reference parses, and ``default_config(<stem>)`` reproduces each file's inference
+    keys one by one (view count, batch size, line filter, pose ranges, pre-align block, write_renderings)."""
+    import dataclasses
+
     from mvlm_amd import config
 
     ref = Path("/root/reference/configs")
     if not ref.exists():
         pytest.skip("reference checkout not present")
-    for f in sorted(ref.glob("*.json")):
+    files = sorted(ref.glob("*.json"))
+    assert sorted(f.stem for f in files) == sorted(config.REFERENCE_CONFIGS)
+    for f in files:
         cfg = config.load_config(f)
         assert cfg.n_landmarks in (73, 84) and cfg.in_channels in (1, 2, 3, 4)
+        mine = config.load_config(config.default_config(f.stem))
+        assert dataclasses.asdict(mine) == dataclasses.asdict(cfg), f.name
+        raw = json.loads(f.read_text())
+        d = config.default_config(f.stem)
+        for block in ("process_3d", "pre-align"):
+            assert d[block] == raw[block], (f.name, block)
+        assert d["data_loader"]["args"]["n_views"] == raw["data_loader"]["args"]["n_views"]
+
+
+def test_default_config_carries_each_files_pre_align():
+    from mvlm_amd import config
+    from mvlm_amd.utils.prealign import is_active
+
+    d = config.default_config("BU_3DFE", "depth")           # BASELINE configs[0]
+    assert d["pre-align"]["align_center_of_mass"] is True and d["pre-align"]["scale"] == 20
+    assert d["data_loader"]["args"]["n_views"] == 96
+    assert config.default_config("BU_3DFE", "depth", n_views=8)["data_loader"]["args"]["n_views"] == 8
+    assert config.default_config("BU_3DFE-RGB+depth")["data_loader"]["args"]["n_views"] == 8
+    assert not is_active(config.default_config("DTU3D", "RGB")["pre-align"])
+    assert is_active(config.default_config("DTU3D-RGB_BU3DFE_RAW")["pre-align"])
+    cfg = config.load_config(config.default_config("DTU3D-RGB_Artec3D"))
+    assert cfg.write_renderings and cfg.pre_align["write_pre_aligned"] and cfg.pre_align["rot_x"] == -90
+    with pytest.raises(ValueError, match="no reference config"):
+        config.default_config("DTU3D", "bogus")
+
+
+def test_unaligned_copy_is_undone_by_the_pre_align_block():
+    from mvlm_amd import config
+    from mvlm_amd.utils.prealign import aligned, is_active, landmarks_to_original_space
+    from mvlm_amd.utils.synthetic import face_like_mesh, unaligned_copy
+
+    mesh = face_like_mesh(20, 8)
+    for stem in ("BU_3DFE-depth", "DTU3D-depth-MRI", "DTU3D-RGB_Artec3D", "DTU3D-RGB_infinite"):
+        block = config.default_config(stem)["pre-align"]
+        raw = unaligned_copy(mesh, block)
+        back = aligned(raw, block)
+        assert back is not raw and back.to_original is not None and is_active(block)
+        centre = mesh.verts.astype(np.float64).mean(0) if block["align_center_of_mass"] else 0.0
+        np.testing.assert_allclose(back.verts, mesh.verts - centre, atol=2e-3)
+        np.testing.assert_allclose(landmarks_to_original_space(back.verts, back.to_original), raw.verts,
+                                   atol=2e-3 / float(block["scale"]) + 1e-5)
+        assert aligned(back, block) is back          # never applied twice
+    assert aligned(mesh, config.default_config("DTU3D", "RGB")["pre-align"]) is mesh
 
 
 def test_packed_weights_reproduce_conv(tmp_path):
@@ -401,6 +450,28 @@ def test_prealign_round_trip():
     back = landmarks_to_original_space(out.verts.astype(np.float64), m)
     np.testing.assert_allclose(back, verts, atol=1e-4)
     assert np.array_equal(prealign_matrix(verts, dict(scale=1)), np.eye(4))
+
+
+def test_prealign_equals_the_oracles_call_sequence():
+    """Product (closed form S*Ry*Rx*Rz, utils/prealign.py) against the oracle's statement-by-statement vtkTransform
+    sequence (oracle/prealign.py, utils3d.py:465-527) for every pre-align block the reference's configs hold."""
+    from mvlm_amd import config
+    from mvlm_amd.utils.mesh_io import Mesh
+    from mvlm_amd.utils.prealign import apply_prealign, landmarks_to_original_space
+    from oracle import prealign as opre
+
+    rs = np.random.RandomState(5)
+    verts = (rs.standard_normal((200, 3)) * 4 + [6, -3, 2]).astype(np.float32)
+    blocks = [config.default_config(stem)["pre-align"] for stem in sorted(config.REFERENCE_CONFIGS)]
+    blocks.append(dict(align_center_of_mass=True, rot_x=-35, rot_y=10, rot_z=180, scale=20, write_pre_aligned=False))
+    for block in blocks:
+        out, m = apply_prealign(Mesh(verts, np.array([[0, 1, 2]], np.int32)), block)
+        want, t = opre.pre_transformation(verts, block)
+        np.testing.assert_allclose(m, t, rtol=0, atol=1e-12 * max(1.0, float(block["scale"])))
+        scale = float(np.abs(want).max()) + 1.0
+        np.testing.assert_allclose(out.verts, want, rtol=0, atol=scale * 2.5e-7)   # float32 points on both sides
+        lms = rs.standard_normal((7, 3)) * 50
+        np.testing.assert_allclose(landmarks_to_original_space(lms, m), opre.landmarks_to_original_space(lms, t), atol=1e-9)
 
 
 def test_cli_shards_scans_across_ranks():

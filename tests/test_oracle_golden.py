@@ -23,7 +23,7 @@ def test_state_dict_keys_match_reference():
         nl, mode = tag.split("_", 1)
         mine = arch.state_dict_shapes(int(nl), MODES[mode])
         assert len(ref) == 817
-        assert list(mine.keys()).sort() == list(ref.keys()).sort()
+        assert sorted(mine.keys()) == sorted(ref.keys())
         assert {k: list(v) for k, v in mine.items()} == ref
 
 
