@@ -69,7 +69,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(mesh, poses, sd, chan_sel, n_sample: int, n_workload: int):
+def cpu_baseline(mesh, poses, sd, chan_sel, n_sample: int, n_workload: int, shading: str = "texture"):
     """Time the CPU oracle (a port of the reference path; the reference's own VTK renderer
     cannot run here) on a bounded sample of the same workload, on all of this box's host cores."""
     import torch
@@ -83,7 +83,8 @@ def cpu_baseline(mesh, poses, sd, chan_sel, n_sample: int, n_workload: int):
     np.random.seed(1)
     log(f"cpu_baseline: {n_sample} views on {cores} threads ...")
     t0 = time.time()
-    opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, sub, sd, chan_sel, batch_size=2, timings=timings)
+    opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, sub, sd, chan_sel, batch_size=2, timings=timings,
+                       shading=shading)
     dt = time.time() - t0
     return {"value": round(n_sample / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
             "sample": f"{n_sample} of the workload's {n_workload} views through the CPU oracle (software rasteriser + "
@@ -321,6 +322,15 @@ def main():
                                   device_batch=args.device_batch)
         nl, c = pipe.get_lm_count(), cfg.in_channels
     pipe.renderer_3d.n_views = n_total
+    if not fusion_only:
+        from mvlm_amd.utils.prealign import aligned, is_active
+        from mvlm_amd.utils.synthetic import unaligned_copy
+
+        if is_active(pipe.pre_align):
+            # the config file carries a pre-align block (BU_3DFE-depth.json: centre of mass + scale 20): the scan is the
+            # raw one that block is written for, brought into the view box the way the product does at load time
+            mesh = aligned(unaligned_copy(mesh, pipe.pre_align), pipe.pre_align)
+            log(f"pre-align block of {spec['json']} applied: {cfg.pre_align}")
     np.random.seed(0)
     poses = pipe.renderer_3d.generate_3d_transformations() if rank == 0 else None
     poses = parallel.broadcast_array(poses, (n_total, 6), device=local_rank)
@@ -337,7 +347,8 @@ def main():
 
     def step():
         np.random.seed(1)
-        return pipe.predict_mesh_device(mesh, poses)
+        landmarks, err = pipe.predict_mesh_device(mesh, poses)
+        return pipe._to_original(mesh, landmarks), err
 
     if args.cnn_execution and not fusion_only:
         g, cc = (int(v) for v in args.cnn_execution.split(","))
@@ -516,7 +527,8 @@ def main():
         n_cpu = min(n_total, 96) if args.cpu_views < 0 else min(args.cpu_views, n_total)
         if n_cpu > 0 and not fusion_only:
             sd = weights.synthetic_state_dict(nl, c, seed=0)
-            cpu = cpu_baseline(mesh, poses, sd, arch.CHANNEL_SELECT[cfg.image_channels], n_cpu, n_total)
+            cpu = cpu_baseline(mesh, poses, sd, arch.CHANNEL_SELECT[cfg.image_channels], n_cpu, n_total,
+                               shading="geometry" if "geometry" in cfg.image_channels else "texture")
         per_gpu = f"{n_local}" if world == 1 else f"{n_total // world}" + ("" if n_total % world == 0 else "+")
         what = (f"configs[{spec['index']}] {spec['json']}" if spec["json"] else
                 f"configs[{spec['index']}] MediaPipe-shaped fusion stress (synthetic 2-D landmarks, no in-scope CNN)")
