@@ -45,7 +45,17 @@
 // 84 output channels (conv6 / conv10 of the 84-landmark network) = 64 + 16 + 4 rows: no padding to 96
 #define MVLM_CONV_VARIANTS_G12(X) \
     X(26, "conv3x3_c84_t8x32", Cfg<84, 32, 8, 1, 3, 4>)
+// 8x16-pixel tiles with 8-channel chunks (round 3).  c32k8: the 32 x (8x16) tile in 30 KB of LDS instead of 60 - five
+// workgroups per CU instead of two, so the 768 workgroups of a 64x64 level at 12 views are resident at once (no
+// half-empty second round): -12..14 % on the 128->64 / 64->64 layers there, -12 % on 256->128 @16x16 at 96 views.
+// c64k8: 64 channels on the same pixel tile (halo 10 x 18 instead of 6 x 34 pixels per channel): -4.5 % on 256->128 @64x64
+// at 12 views, -5 % on the 32x32 level at 96 views.  Measured and dropped: 128 x (8x16), 64 x (8x16) with 4-channel
+// chunks, 32 x (4x32) / 64 x (4x32) with 8-channel chunks, 32 x (8x16) with 4-channel chunks (within 1 % of these),
+// a 64 x (16x32) tile (128 accumulators, +0.7 %), input channels divided over workgroups on the plain tiles (slower).
+#define MVLM_CONV_VARIANTS_G13(X) \
+    X(27, "conv3x3_c32k8_t8x16", Cfg<32, 16, 8, 1, 3, 8>) \
+    X(28, "conv3x3_c64k8_t8x16", Cfg<64, 16, 8, 1, 3, 8>)
 #define MVLM_CONV_VARIANTS(X) \
-    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X)
-#define MVLM_CONV_N_GROUPS 13
+    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X) MVLM_CONV_VARIANTS_G13(X)
+#define MVLM_CONV_N_GROUPS 14
 #endif

@@ -258,6 +258,37 @@ def test_conv_tiles_of_large_device_batches(cin, cout, size, batch):
     assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("variant,name,cin,cout,size,batch", [
+    (27, "conv3x3_c32k8_t8x16", 128, 64, 64, 2), (27, "conv3x3_c32k8_t8x16", 256, 128, 16, 5), (27, "conv3x3_c32k8_t8x16", 64, 32, 128, 1),
+    (28, "conv3x3_c64k8_t8x16", 256, 128, 64, 1), (28, "conv3x3_c64k8_t8x16", 64, 64, 32, 3), (28, "conv3x3_c64k8_t8x16", 128, 64, 16, 2),
+])
+def test_round3_tiles_match_torch(variant, name, cin, cout, size, batch):
+    """Round 3: the 8x16-pixel tiles with 8-channel chunks (half the LDS: more workgroups per CU at small batches), forced
+    onto residual-block shaped layers (pre-BN, residual add) against torch float64."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    rs = np.random.RandomState(cin + size + batch + variant)
+    x = rs.standard_normal((batch, cin, size, size)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32))
+    res = rs.standard_normal((batch, cout, size, size)).astype(np.float32)
+    xd, rd = dev(x), dev(res)
+    yd = torch.empty((batch, cout, size, size), dtype=torch.float32, device="cuda")
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert ctx.lib.mvlm_conv_variant_name(variant).decode() == name
+    ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, variant))
+    try:
+        ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
+                                      p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())))
+    finally:
+        ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, -1))
+    t = torch.relu(torch.from_numpy(x).double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
+                   + torch.from_numpy(pre[1]).double()[None, :, None, None])
+    want = (torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None, 1, 1) + torch.from_numpy(res).double()).numpy()
+    assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+
+
 def test_visualize_image_stack_writes_the_views(tmp_path):
     """--visualize-method (general_pipeline.py:133-146): one PNG per view, RGB planes * 255 as uint8."""
     from PIL import Image

