@@ -92,6 +92,14 @@ struct Strip4 {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 };
 
+// Split-K tiles: what a lane keeps from the start of the kernel for its share of the epilogue (see conv_mfma_kernel)
+struct SplitKTail {
+    bool ok = false;
+    unsigned b = 0, pix = 0;
+    int y = 0, x = 0;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+};
+
 // Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
 // padding elements read element 0 and are zeroed at write time): a branch around a load makes
 // the compiler wait for each one separately.
@@ -389,6 +397,39 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         cb0 = kp * span;
         cb1 = cb0 + span;
     }
+    // Split-K tiles (one 32x32 tile per workgroup, no K parts over workgroups): after the reduction wave w owns the
+    // accumulator registers 4w..4w+3 = the channels co0 + 8w + 4 half + (0..3) and finishes them alone, so the four
+    // waves' epilogues run side by side.  Its residual values are requested HERE, before the K loop: the epilogue of
+    // these latency-bound launches then adds and stores without a memory round trip of its own.
+    SplitKTail sk;
+    if constexpr (C::SPLITK) {
+        if (a.kparts <= 1) {
+            const int rr = l31 / C::TW;
+            const int b = b0 + rr / C::TRI;
+            const int y = y0 + rr % C::TRI, x = x0 + l31 % C::TW;
+            sk.ok = C::NIMG == 1 ? true : (b < a.B);
+            sk.b = sk.ok ? unsigned(b) : 0u;
+            sk.pix = unsigned(y * a.W + x);
+            sk.y = y;
+            sk.x = x;
+            const unsigned HWo = unsigned(a.H) * unsigned(a.W);
+            const int cl = co0 + 8 * wave + 4 * half;  // this lane's first channel
+            if (a.res1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cs = (cl + j < a.cout) ? cl + j : 0;  // padded channel rows read inside the tensor
+                    sk.res[j] = a.res1[(size_t(sk.b) * a.res1_ctot + a.res1_coff + cs) * HWo + sk.pix];
+                }
+                if (a.res2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cs = (cl + j < a.cout) ? cl + j : 0;
+                        sk.res[j] += a.res2[(size_t(sk.b) * a.res2_ctot + a.res2_coff + cs) * HWo + sk.pix];
+                    }
+                }
+            }
+        }
+    }
     static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true>(a, cb0, tid, HWin, sbn, goff, woff_g, regs, smem); });
     if (a.pre_scale != nullptr) {
         for (int i = tid; i < a.cin_pad; i += 256) {
@@ -435,8 +476,85 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         return;
     }
 #endif
+    if constexpr (C::SPLITK && !AMAX) {
+        if (a.kparts <= 1) {
+            // every wave leaves its partial tile in LDS, then wave w adds registers 4w..4w+3 of the four partials in wave
+            // order ((w0 + w1) + w2) + w3 - the order of the single-wave reduction below, bit for bit - and finishes them
+            static_assert(!C::SPLITK || 2 * C::STAGE >= 4 * 16 * 64, "the four partial tiles must fit the two stages");
+            __syncthreads();  // every wave is done reading the stages: reuse them as the exchange buffer
+            float* const red = smem;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+            __syncthreads();
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = red[(0 * 16 + 4 * wave + j) * 64 + lane];
+                t += red[(1 * 16 + 4 * wave + j) * 64 + lane];
+                t += red[(2 * 16 + 4 * wave + j) * 64 + lane];
+                t += red[(3 * 16 + 4 * wave + j) * 64 + lane];
+                v[j] = t;
+            }
+            const unsigned HWo = unsigned(a.H) * unsigned(a.W);
+            const int cl = co0 + 8 * wave + 4 * half;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + cl);  // padded to cout_pad: never out of bounds
+            if (a.post_scale) {
+                ps4 = *reinterpret_cast<const f32x4*>(a.post_scale + cl);
+                pt4 = *reinterpret_cast<const f32x4*>(a.post_shift + cl);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (a.bias) v[j] += bias4[j];
+                if (a.post_scale) v[j] = fmaxf(fmaf(v[j], ps4[j], pt4[j]), 0.f);
+            }
+            if (a.out_raw) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (sk.ok && cl + j < a.cout) a.out_raw[(size_t(sk.b) * a.raw_ctot + a.raw_coff + cl + j) * HWo + sk.pix] = v[j];
+            }
+            if (a.res1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += sk.res[j];
+            }
+            if (a.out) {
+                if (!a.up_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (sk.ok && cl + j < a.cout) a.out[(size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * HWo + sk.pix] = v[j];
+                } else if (a.up_out == 2) {
+                    const unsigned o2 = unsigned(2 * sk.y + a.sub_y) * unsigned(2 * a.W) + unsigned(2 * sk.x + a.sub_x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (sk.ok && cl + j < a.cout) a.out[(size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * (4u * HWo) + o2] = v[j];
+                } else {
+                    // hourglass up-path: the value goes to its 2x2 block of the skip tensor, added in place (:334-359)
+                    const unsigned W2 = 2u * unsigned(a.W);
+                    const unsigned o2 = unsigned(2 * sk.y) * W2 + unsigned(2 * sk.x);
+                    float2 s0[4], s1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cs = (cl + j < a.cout) ? cl + j : 0;
+                        const float* const ps = a.skip + (size_t(sk.b) * a.skip_ctot + a.skip_coff + cs) * (4u * HWo) + o2;
+                        s0[j] = *reinterpret_cast<const float2*>(ps);
+                        s1[j] = *reinterpret_cast<const float2*>(ps + W2);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (sk.ok && cl + j < a.cout) {
+                            float* const po = a.out + (size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * (4u * HWo) + o2;
+                            *reinterpret_cast<float2*>(po) = make_float2(v[j] + s0[j].x, v[j] + s0[j].y);
+                            *reinterpret_cast<float2*>(po + W2) = make_float2(v[j] + s1[j].x, v[j] + s1[j].y);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     if constexpr (C::SPLITK) {
-        // add the four waves' partial tiles in wave order (deterministic), wave 0 finishes alone
+        // (input channels also divided over workgroups, or a fused-argmax launch) add the four waves' partial tiles in wave
+        // order (deterministic), wave 0 finishes alone
         __syncthreads();  // every wave is done reading the stages: reuse them as the exchange buffer
         float* red = smem;
         if (wave > 0) {

@@ -29,7 +29,26 @@ CASES = [  # name, cin, cout, size, k, batch, pre-BN, residual, bias+post-BN
 ]
 
 
+SMALL = [  # the latency-bound levels of a 12-view batch (MVLM_PHASE_CASES=small)
+    ("block conv1  256->128 @ 32 B12", 256, 128, 32, 3, 12, True, True, False),
+    ("block conv2  128-> 64 @ 32 B12", 128, 64, 32, 3, 12, True, True, False),
+    ("block conv1  256->128 @ 16 B12", 256, 128, 16, 3, 12, True, True, False),
+    ("block conv2  128-> 64 @ 16 B12", 128, 64, 16, 3, 12, True, True, False),
+    ("block conv3   64-> 64 @ 16 B12", 64, 64, 16, 3, 12, True, True, False),
+    ("block conv1  256->128 @  8 B12", 256, 128, 8, 3, 12, True, True, False),
+    ("block conv2  128-> 64 @  8 B12", 128, 64, 8, 3, 12, True, True, False),
+    ("block conv3   64-> 64 @  8 B12", 64, 64, 8, 3, 12, True, True, False),
+    ("block conv1  256->128 @  4 B12", 256, 128, 4, 3, 12, True, True, False),
+    ("block conv3   64-> 64 @  4 B12", 64, 64, 4, 3, 12, True, True, False),
+    ("block conv1  256->128 @ 64 B12", 256, 128, 64, 3, 12, True, True, False),
+    ("block conv2  128-> 64 @ 64 B12", 128, 64, 64, 3, 12, True, True, False),
+]
+
+
 def main():
+    global CASES
+    if os.environ.get("MVLM_PHASE_CASES") == "small":
+        CASES = SMALL
     ctx = _lib.get_context(0)
     buf = torch.zeros(4, dtype=torch.int64, device="cuda")
     os.environ["MVLM_CONV_TIMING_BUF"] = hex(buf.data_ptr())
