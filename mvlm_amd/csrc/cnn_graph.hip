@@ -17,6 +17,8 @@
 //
 // All views of a batch go through each layer together (pixels of all views form the GEMM's
 // N dimension), so even the 4x4 hourglass level fills MFMA tiles.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -197,7 +199,7 @@ struct Exec {
         }
         if (st.profiling) {
             hipEventRecord(e1, ctx->cur_stream());
-            const double flops = 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(S) * S * B;
+            const double flops = 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(S) * S * B * a.n_par;
             st.prof.push_back({slot, variant, flops, e0, e1});
         }
         return 0;
@@ -278,6 +280,18 @@ struct Exec {
         release(t2);
         if (pooled && !hi && !fused_pool && !dry && !rc && mvlm_launch_maxpool2(ctx, y.p, B * cout, S, S, pooled->p)) rc = 1;
         return y;
+    }
+
+    // the four parity slots of conv11 differ in their weights only (same shapes, one bias): they can share a launch
+    bool parity_weights_uniform(int slot0) const {
+        const int32_t* r0 = d(slot0);
+        for (int q = 1; q < 4; ++q) {
+            const int32_t* r = d(slot0 + q);
+            if (!r[0] || r[1] != r0[1] || r[2] != r0[2] || r[3] != r0[3] || r[4] != r0[4] || r[5] != r0[5] || (r[7] < 0) != (r0[7] < 0)) return false;
+            for (int k = 8; k <= 11; ++k)
+                if (r[k] >= 0 || r0[k] >= 0) return false;  // plain conv + bias layers
+        }
+        return true;
     }
 
     // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
@@ -458,13 +472,22 @@ struct Exec {
                 av = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
                 ai = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
             }
-            for (int pl = 0; pl < (parity ? 4 : 1); ++pl) {
+            // the four parities share their input tiles: ONE launch with the parities of a tile on neighbouring workgroups
+            // (ConvArgs::n_par); MVLM_CONV11_PARITY_LAUNCHES=4 keeps one launch per parity (experiments)
+            static const bool split_launches = [] { const char* e = getenv("MVLM_CONV11_PARITY_LAUNCHES"); return e && e[0] == '4'; }();
+            const bool one_launch = parity && !split_launches && parity_weights_uniform(SLOT_PARITY);
+            for (int pl = 0; pl < (parity && !one_launch ? 4 : 1); ++pl) {
                 ConvArgs a;
                 Tensor xin = x10;
                 if (parity) {
                     a.sub_y = pl >> 1;
                     a.sub_x = pl & 1;
                     a.up_out = 2;
+                    if (one_launch) {
+                        a.n_par = 4;
+                        for (int q = 0; q < 4; ++q) a.w_par[q] = blob(d(SLOT_PARITY + q)[6]);
+                        a.amax_par_stride = parts1;
+                    }
                 } else {
                     a.up_in = 1;
                     xin.S = 256;

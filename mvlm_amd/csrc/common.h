@@ -91,6 +91,11 @@ struct ConvArgs {
     // 2: out is [B][out_ctot][2H][2W]; the value goes to pixel (2y + sub_y, 2x + sub_x) only
     int up_out = 0;
     int sub_y = 0, sub_x = 0;  // up_out == 2 / ksize == 2: output parity = 2x2 window offset in the halo tile
+    // ksize == 2, up_out == 2: all four output parities in one launch (grid x 4): parity pl = 2 sub_y + sub_x uses the
+    // weights w_par[pl] and, with a fused argmax, the partials from amax_part0 + pl * amax_par_stride
+    int n_par = 1;
+    const float* w_par[4] = {nullptr, nullptr, nullptr, nullptr};
+    int amax_par_stride = 0;
     const float* skip = nullptr;
     int skip_ctot = 0, skip_coff = 0;
     // split-K tiles only: input channels divided over `kparts` workgroups per output tile (set by the variant id);

@@ -276,7 +276,7 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
 //   the other stage; ONE barrier per chunk.  The kernel may use the whole 512-register file
 //   (launch bounds 256,1), so nothing spills and the 128 accumulators stay in registers.
 template <class C, bool AMAX>
-__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
+__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a_in, const int tiles_x, const int tiles_y,
                                                            const int cout_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -294,6 +294,23 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    // conv11 as four 2x2 parity convolutions in ONE launch (ConvArgs::n_par == 4): the four parities of a tile are
+    // neighbouring workgroups of one XCD, so the low-resolution input tile they all stage comes out of that L2 once, and
+    // a small batch gives the chip 4x the workgroups per launch.  Everything that depends on the parity is patched into
+    // a private copy of the arguments (wave-uniform values); other kernels use the launch arguments as they are.
+    ConvArgs a_par;
+    if constexpr (C::KS == 2) {
+        a_par = a_in;
+        if (a_in.n_par == 4) {
+            const int pl = lid & 3;
+            lid >>= 2;
+            a_par.sub_y = pl >> 1;
+            a_par.sub_x = pl & 1;
+            a_par.w = a_in.w_par[pl];
+            a_par.amax_part0 = a_in.amax_part0 + pl * a_in.amax_par_stride;
+        }
+    }
+    const ConvArgs& a = C::KS == 2 ? a_par : a_in;
     // split-K tiles may also split the input channels over `kparts` workgroups (grid = tiles x kparts, the parts of a
     // tile adjacent): each sums its channel range, the last one to finish adds the partial tiles in part order
     int kp = 0;
@@ -1064,6 +1081,14 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
         MVLM_REQUIRE(ctx, !a.out && !a.out_raw && !a.pool_out, "conv: a fused-argmax launch does not materialise the heatmap");
     }
     long nblk = long(tiles_x) * tiles_y * tiles_b * cout_tiles;
+    if (a.n_par != 1) {
+        MVLM_REQUIRE(ctx, a.n_par == 4 && C::KS == 2 && a.up_out == 2, "conv: four parities per launch are a 2x2-kernel feature");
+        MVLM_REQUIRE(ctx, a.w_par[0] && a.w_par[1] && a.w_par[2] && a.w_par[3], "conv: parity weights missing");
+        MVLM_REQUIRE(ctx, !a.amax_val || (a.amax_par_stride >= tiles_x * tiles_y * 4 &&
+                                          a.amax_part0 + 3 * a.amax_par_stride + tiles_x * tiles_y * 4 <= a.amax_parts),
+                     "conv: argmax partial range mismatch (four parities)");
+        nblk *= 4;
+    }
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
     a.kparts = a.kparts > 1 ? a.kparts : 1;
     if (a.kparts > 1) {
