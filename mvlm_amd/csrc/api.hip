@@ -78,7 +78,18 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
     delete ctx;
 }
 
-extern "C" const char* mvlm_last_error(mvlm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// The calling thread's last failure on this context (valid until that thread's next failing call); a thread without
+// one of its own gets a private copy of the context's latest message - never a pointer into a string another thread
+// may be reassigning.
+extern "C" const char* mvlm_last_error(mvlm_ctx* ctx) {
+    if (!ctx) return "null context";
+    if (mvlm_thread_error_ctx() != ctx) {
+        std::lock_guard<std::mutex> lock(ctx->err_mu);
+        mvlm_thread_error() = ctx->err;
+        mvlm_thread_error_ctx() = ctx;
+    }
+    return mvlm_thread_error().c_str();
+}
 
 extern "C" int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream) {
     MVLM_ENTER(ctx);
@@ -95,16 +106,16 @@ extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {
 extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
                                 const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
                                 mvlm_mesh** out) {
-    MVLM_ENTER(ctx);
+    // Called from reader threads while another thread launches kernels on this context.  The host work - index
+    // validation (O(3T)), waiting for a staging slot, a possible hipHostMalloc, the 10-25 MB memcpy into pinned memory -
+    // runs under the upload mutex only; the context mutex every launch entry point takes is held just for the pool
+    // pick, the asynchronous copies and the event records.
     MVLM_REQUIRE(ctx, out, "mesh_upload: null output");
     *out = nullptr;
     MVLM_REQUIRE(ctx, verts_host && tris_host && n_verts > 0 && n_tris > 0, "mesh_upload: mesh does not contain any points");
     MVLM_REQUIRE(ctx, !tex_host || (tex_h > 0 && tex_w > 0), "mesh_upload: bad texture size");
     for (long i = 0; i < 3l * n_tris; ++i)
         MVLM_REQUIRE(ctx, tris_host[i] >= 0 && tris_host[i] < n_verts, "mesh_upload: triangle index out of range");
-    MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    // Sizes and the pinned staging slot (two slots alternate; a slot is reused once the copies out of it are done)
-    if (!ctx->upload_stream) MVLM_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     const bool with_tex = tex_host && uvs_host;
     const void* src[4] = {verts_host, uvs_host, tris_host, with_tex ? tex_host : nullptr};
     const size_t bytes[4] = {size_t(n_verts) * 12, uvs_host ? size_t(n_verts) * 8 : 0, size_t(n_tris) * 12,
@@ -114,6 +125,11 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
         off[i] = total;
         total += (bytes[i] + 255) / 256 * 256;
     }
+
+    std::lock_guard<std::mutex> upload_lock(ctx->upload_mu);
+    MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    // the pinned staging slot (two slots alternate; a slot is reused once the copies out of it are done)
+    if (!ctx->upload_stream) MVLM_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     const int slot = ctx->upload_stage_next;
     ctx->upload_stage_next ^= 1;
     if (ctx->upload_stage_done[slot]) MVLM_CHECK_HIP(ctx, hipEventSynchronize(ctx->upload_stage_done[slot]));
@@ -134,46 +150,49 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     m->n_tris = n_tris;
     void** dst[4] = {(void**)&m->verts, (void**)&m->uvs, (void**)&m->tris, (void**)&m->tex};
     bool ok = true;
-    for (int i = 0; i < 4 && ok; ++i) {
-        if (!bytes[i]) continue;
-        // the OLDEST pooled buffer that fits: its previous owner's work finished long ago, so the wait below is a no-op
-        // and the copy really runs beside the current scan's kernels
-        int pick = -1;
-        for (int k = 0; k < int(ctx->mesh_pool.size()); ++k) {
-            const size_t c = ctx->mesh_pool[size_t(k)].cap;
-            if (c >= bytes[i] && c <= 4 * bytes[i] + (1u << 20)) {
-                pick = k;
-                break;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);  // pool, event list: shared with the launch entry points
+        for (int i = 0; i < 4 && ok; ++i) {
+            if (!bytes[i]) continue;
+            // the OLDEST pooled buffer that fits: its previous owner's work finished long ago, so the wait below is a no-op
+            // and the copy really runs beside the current scan's kernels
+            int pick = -1;
+            for (int k = 0; k < int(ctx->mesh_pool.size()); ++k) {
+                const size_t c = ctx->mesh_pool[size_t(k)].cap;
+                if (c >= bytes[i] && c <= 4 * bytes[i] + (1u << 20)) {
+                    pick = k;
+                    break;
+                }
             }
-        }
-        if (pick >= 0) {
-            const auto e = ctx->mesh_pool[size_t(pick)];
-            ctx->mesh_pool.erase(ctx->mesh_pool.begin() + pick);
-            ctx->mesh_pool_bytes -= e.cap;
-            *dst[i] = e.p;
-            m->cap[i] = e.cap;
-            m->waited[i] = e.freed;  // returned to the event list with the mesh
-            if (e.freed && hipStreamWaitEvent(ctx->upload_stream, e.freed, 0) != hipSuccess) ok = false;
-        } else {
-            m->cap[i] = (bytes[i] + 65535) / 65536 * 65536;
-            if (hipMalloc(dst[i], m->cap[i]) != hipSuccess) {
-                *dst[i] = nullptr;
-                m->cap[i] = 0;
-                ok = false;
+            if (pick >= 0) {
+                const auto e = ctx->mesh_pool[size_t(pick)];
+                ctx->mesh_pool.erase(ctx->mesh_pool.begin() + pick);
+                ctx->mesh_pool_bytes -= e.cap;
+                *dst[i] = e.p;
+                m->cap[i] = e.cap;
+                m->waited[i] = e.freed;  // returned to the event list with the mesh
+                if (e.freed && hipStreamWaitEvent(ctx->upload_stream, e.freed, 0) != hipSuccess) ok = false;
+            } else {
+                m->cap[i] = (bytes[i] + 65535) / 65536 * 65536;
+                if (hipMalloc(dst[i], m->cap[i]) != hipSuccess) {
+                    *dst[i] = nullptr;
+                    m->cap[i] = 0;
+                    ok = false;
+                }
             }
+            if (ok && hipMemcpyAsync(*dst[i], stage + off[i], bytes[i], hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) ok = false;
         }
-        if (ok && hipMemcpyAsync(*dst[i], stage + off[i], bytes[i], hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) ok = false;
-    }
-    if (with_tex) {
-        m->tex_h = tex_h;
-        m->tex_w = tex_w;
-    }
-    if (ok) {
-        if (!ctx->upload_stage_done[slot]) ctx->upload_stage_done[slot] = ctx->take_event();
-        m->ready = ctx->take_event();
-        ok = ctx->upload_stage_done[slot] && m->ready &&
-             hipEventRecord(ctx->upload_stage_done[slot], ctx->upload_stream) == hipSuccess &&
-             hipEventRecord(m->ready, ctx->upload_stream) == hipSuccess;
+        if (with_tex) {
+            m->tex_h = tex_h;
+            m->tex_w = tex_w;
+        }
+        if (ok) {
+            if (!ctx->upload_stage_done[slot]) ctx->upload_stage_done[slot] = ctx->take_event();
+            m->ready = ctx->take_event();
+            ok = ctx->upload_stage_done[slot] && m->ready &&
+                 hipEventRecord(ctx->upload_stage_done[slot], ctx->upload_stream) == hipSuccess &&
+                 hipEventRecord(m->ready, ctx->upload_stream) == hipSuccess;
+        }
     }
     if (!ok) {
         (void)hipStreamSynchronize(ctx->upload_stream);

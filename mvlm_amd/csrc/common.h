@@ -176,6 +176,16 @@ struct RenderProfileRec {
     hipEvent_t e0, e1;
 };
 
+// per-thread copy of the last error message and the context it belongs to (api.hip: mvlm_last_error)
+inline std::string& mvlm_thread_error() {
+    thread_local std::string s;
+    return s;
+}
+inline const void*& mvlm_thread_error_ctx() {
+    thread_local const void* c = nullptr;
+    return c;
+}
+
 struct mvlm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -209,6 +219,7 @@ struct mvlm_ctx {
     size_t mesh_pool_bytes = 0;
     // mesh uploads: pinned staging (two slots) -> hipMemcpyAsync on a stream of their own, so a reader thread's upload of
     // the next scan runs beside the current scan's kernels and never makes a host wait for the launch stream
+    std::mutex upload_mu;  // staging slots + upload stream; taken before `mu`, never the other way round
     hipStream_t upload_stream = nullptr;
     void* upload_stage[2] = {nullptr, nullptr};
     size_t upload_stage_cap[2] = {0, 0};
@@ -225,12 +236,23 @@ struct mvlm_ctx {
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
         return e;
     }
-    int fail(const std::string& m) {
-        err = m;
-        return 1;
-    }
+    // The message of a failed call belongs to the calling thread: reader threads upload meshes while another thread
+    // launches (predict_files), and both may fail.  `err` keeps the context's latest message (under err_mu) for a
+    // thread that has none of its own; mvlm_last_error hands out the calling thread's copy.
+    std::mutex err_mu;
+    int fail(const std::string& m);
     void* get_scratch(const char* name, size_t bytes);
 };
+
+inline int mvlm_ctx::fail(const std::string& m) {
+    {
+        std::lock_guard<std::mutex> lock(err_mu);
+        err = m;
+    }
+    mvlm_thread_error() = m;
+    mvlm_thread_error_ctx() = this;
+    return 1;
+}
 
 // a mesh's device copy is complete once its `ready` event has fired: consumers make their stream wait for it
 inline int mvlm_mesh_wait_ready(mvlm_ctx* ctx, const mvlm_mesh* m, hipStream_t stream) {

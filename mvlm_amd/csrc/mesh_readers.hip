@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -106,6 +107,14 @@ struct Scan {
 std::string lower(std::string s) {
     for (auto& c : s) c = char(tolower((unsigned char)c));
     return s;
+}
+
+// A parsed number used as an index: strtod accepts "nan", "inf" and 1e300, and casting those to an integer type is
+// undefined behaviour (on x86 it yields LLONG_MIN, which then passes a "v >= n" test).  Finite, whole and inside
+// [0, 2^31) or -1: every caller's own range check rejects the -1.
+long long to_index(double d) {
+    if (!std::isfinite(d) || d < 0.0 || d >= 2147483648.0 || d != std::floor(d)) return -1;
+    return (long long)d;
 }
 
 void fan(const std::vector<long long>& ids, std::vector<int32_t>* tris) {
@@ -486,10 +495,14 @@ int read_vtk(const std::vector<char>& data, mvlm_obj* o, std::string* msg) {
                     return MVLM_OBJ_ERR_SYNTAX;
                 }
                 for (size_t c = 0; c + 1 < offs.size(); ++c) {
-                    const long long a = (long long)offs[c], b = (long long)offs[c + 1];
+                    const long long a = to_index(offs[c]), b = to_index(offs[c + 1]);
                     if (a < 0 || b < a || b > (long long)vals.size()) { *msg = "bad VTK cell offsets"; return MVLM_OBJ_ERR_SYNTAX; }
                     ids.clear();
-                    for (long long k = a; k < b; ++k) ids.push_back((long long)vals[size_t(k)]);
+                    for (long long k = a; k < b; ++k) {
+                        const long long id = to_index(vals[size_t(k)]);
+                        if (id < 0) { *msg = "VTK cell references a point that does not exist"; return MVLM_OBJ_ERR_INDEX; }
+                        ids.push_back(id);
+                    }
                     if (kw == "polygons") fan(ids, &o->tris);
                     else
                         for (size_t k = 0; k + 2 < ids.size(); ++k) {  // strip: alternate the winding
@@ -503,10 +516,14 @@ int read_vtk(const std::vector<char>& data, mvlm_obj* o, std::string* msg) {
                 if (!vtk_values(&sc, binary, "int", size, &vals)) { *msg = "bad VTK cell list"; return MVLM_OBJ_ERR_SYNTAX; }
                 size_t i = 0;
                 for (long long c = 0; c < n && i < vals.size(); ++c) {
-                    const long long m = (long long)vals[i++];
+                    const long long m = to_index(vals[i++]);
                     if (m < 0 || i + size_t(m) > vals.size()) { *msg = "bad VTK cell list"; return MVLM_OBJ_ERR_SYNTAX; }
                     ids.clear();
-                    for (long long k = 0; k < m; ++k) ids.push_back((long long)vals[i++]);
+                    for (long long k = 0; k < m; ++k) {
+                        const long long id = to_index(vals[i++]);
+                        if (id < 0) { *msg = "VTK cell references a point that does not exist"; return MVLM_OBJ_ERR_INDEX; }
+                        ids.push_back(id);
+                    }
                     if (kw == "polygons") fan(ids, &o->tris);
                     else
                         for (size_t k = 0; k + 2 < ids.size(); ++k) {
@@ -662,15 +679,15 @@ int read_wrl(const std::vector<char>& data, mvlm_obj* o, std::string* msg) {
     };
     for (size_t i = 0; i < last.idx.size(); ++i) {
         const double dv = last.idx[i];
-        if (dv < 0) {
+        if (dv < 0) {  // -1 closes a face (NaN is not < 0: it goes on to the index check)
             flush();
             continue;
         }
-        const long long v = (long long)dv;
-        if (v >= n_pts) { *msg = "VRML face references a point that does not exist"; return MVLM_OBJ_ERR_INDEX; }
+        const long long v = to_index(dv);
+        if (v < 0 || v >= n_pts) { *msg = "VRML face references a point that does not exist"; return MVLM_OBJ_ERR_INDEX; }
         long long tc = -1;
         if (per_corner_tex) {
-            tc = (long long)last.tidx[i];
+            tc = to_index(last.tidx[i]);
             if (tc < 0 || tc >= n_tex) { *msg = "VRML face references a texture coordinate that does not exist"; return MVLM_OBJ_ERR_INDEX; }
         } else if (per_point_tex) {
             tc = v;

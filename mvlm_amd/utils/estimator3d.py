@@ -105,7 +105,7 @@ class HipEstimator3D:
         alive at the same time (several scans sharing one network pass) need staging and device buffers of their own."""
         torch, dev = self._torch()
         plan = {"expected": self.expected_counts(n_landmarks, n_views), "rng_state": np.random.get_state(),
-                "draws_fn": draws_fn, "draws_dev": None, "ready": None}
+                "draws_fn": draws_fn, "draws_dev": None, "ready": None, "consumed": None}
         if plan["expected"] is not None:
             verbose, self.verbose = self.verbose, False  # "Not enough points" is reported by the pass that counts
             try:
@@ -134,14 +134,17 @@ class HipEstimator3D:
             if bufs is None:
                 bufs = self._draw_bufs[key] = (torch.empty((n_landmarks, 8), dtype=torch.int32).pin_memory(),
                                                torch.empty((n_landmarks, 8), dtype=torch.int32, device=dev),
-                                               torch.cuda.Event())
-            pinned, dev_buf, event = bufs
+                                               torch.cuda.Event(), torch.cuda.Event())
+            pinned, dev_buf, event, consumed = bufs
             event.synchronize()  # the previous upload out of this staging buffer has completed
             pinned.copy_(torch.from_numpy(draws))
             with torch.cuda.stream(self._upload_stream):
+                # the previous solve that read this device table (compute stream) comes first: a caller that plans the
+                # next scan's draws before synchronising must not overwrite a table a queued solve has yet to read
+                self._upload_stream.wait_event(consumed)
                 dev_buf.copy_(pinned, non_blocking=True)
                 event.record(self._upload_stream)
-            plan["draws_dev"], plan["ready"] = dev_buf, event
+            plan["draws_dev"], plan["ready"], plan["consumed"] = dev_buf, event, consumed
         return plan
 
     def consensus_device(self, landmarks_dev, starts, ends, draws_fn=None, deferred: bool = False, plan=None,
@@ -192,6 +195,8 @@ class HipEstimator3D:
             if plan["ready"] is not None:
                 torch.cuda.current_stream(dev).wait_event(plan["ready"])
             solve(plan["draws_dev"])
+            if plan.get("consumed") is not None:
+                plan["consumed"].record(torch.cuda.current_stream(dev))  # plan_draws waits for it before reusing the table
 
             def verify(counts=None) -> bool:
                 counts = state["counts"] = np.asarray(count.cpu().numpy() if counts is None else counts)

@@ -270,6 +270,18 @@ def test_mesh_readers_under_sanitizers(tmp_path):
         f = tmp_path / f"m{i}{n[1:]}"
         f.write_bytes(bytes(b))
         files.append(f)
+    # indices that strtod accepts but no integer can hold (round-2 advice): rejected, never cast
+    bad_index = []
+    for tag, tok in (("nan", b"nan"), ("inf", b"inf"), ("big", b"1e300"), ("frac", b"1.5")):
+        w = base["a.wrl"].replace(b"coordIndex [", b"coordIndex [ " + tok + b", 1, 2, -1,", 1)
+        assert w != base["a.wrl"]
+        (tmp_path / f"idx_{tag}.wrl").write_bytes(w)
+        v = base["a.vtk"]
+        at = v.find(b"POLYGONS")
+        eol = v.find(b"\n", at) + 1
+        (tmp_path / f"idx_{tag}.vtk").write_bytes(v[:eol] + b"3 " + tok + b" 1 2\n" + v[v.find(b"\n", eol) + 1:])
+        bad_index += [tmp_path / f"idx_{tag}.wrl", tmp_path / f"idx_{tag}.vtk"]
+    files += bad_index
     for ext in (".ply", ".stl", ".vtk", ".wrl"):
         (tmp_path / f"empty{ext}").write_bytes(b"")
         files.append(tmp_path / f"empty{ext}")
@@ -283,3 +295,6 @@ def test_mesh_readers_under_sanitizers(tmp_path):
     for k in range(len(names)):
         assert " ok " in lines[k] and lines[k].endswith("bad_indices=0"), lines[k]
     assert all(("rc=" in ln) or ln.endswith("bad_indices=0") for ln in lines)   # parsed output is always in range
+    for f in bad_index:
+        ln = lines[files.index(f)]
+        assert "rc=" in ln and " ok " not in ln, ln                              # rejected, not silently point 0
