@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mvlm_hip.h"
@@ -133,37 +134,41 @@ void set_err(char* err, int err_len, const std::string& msg) {
     if (err && err_len > 0) snprintf(err, size_t(err_len), "%s", msg.c_str());
 }
 
-}  // namespace
+// ---- chunk-parallel parse --------------------------------------------------------------------------------------
+// The text is cut at line ends into one chunk per thread.  A chunk is parsed on its own: positions and texture
+// coordinates into local arrays, faces as raw index pairs together with the number of elements the chunk had seen when
+// the face came (OBJ's negative indices count back from there).  What needs the whole file - the element bases of a
+// chunk (prefix sum of the counts), the numbering of the (v, vt) corners in order of first use, the first error in file
+// order - follows in one sequential pass over the already parsed faces.  Results are those of a single-threaded parse,
+// byte for byte, for any number of chunks (tests/test_host_logic.py compares 1, 2, 3, 7 threads and the Python statement).
+constexpr long long NO_TEX = -(1ll << 62);
 
-extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int err_len) {
-    if (!path || !out) { set_err(err, err_len, "obj_read: bad arguments"); return MVLM_OBJ_ERR_ARGS; }
-    *out = nullptr;
-    FILE* f = fopen(path, "rb");
-    if (!f) { set_err(err, err_len, std::string("File ") + path + " does not exist."); return MVLM_OBJ_ERR_FILE; }
-    std::vector<char> text;
-    {
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        text.resize(sz > 0 ? size_t(sz) : 0);
-        const size_t got = text.empty() ? 0 : fread(text.data(), 1, text.size(), f);
-        text.resize(got);
-        fclose(f);
-    }
+struct Face {
+    uint32_t first, count;          // corners [first, first + count) of the chunk's corner arrays
+    uint32_t pos_before, tex_before;  // elements this chunk had read when the face came
+};
+
+struct Chunk {
+    const char* begin = nullptr;
+    const char* end = nullptr;
     std::vector<float> pos, tex;
-    std::vector<long long> corner_v, corner_t;
-    std::vector<int32_t> tris;
-    std::vector<int32_t> ids;
-    CornerMap corners;
-    pos.reserve(text.size() / 24);
-    const char* p = text.data();
-    const char* const eof = p + text.size();
-    long line_no = 0;
+    std::vector<long long> cv, ct;  // raw indices as written (1-based or negative), ct = NO_TEX when absent
+    std::vector<Face> faces;
+    long lines = 0;
+    long err_line = 0;              // > 0: a syntax error on that line of the chunk
+    const char* err_what = nullptr;
+};
+
+void parse_chunk(Chunk* c) {
+    const char* p = c->begin;
+    const char* const eof = c->end;
+    c->pos.reserve(size_t(eof - p) / 24);
     const char* tok_s[64];
     const char* tok_e[64];
+    long line_no = 0;
     auto syntax = [&](const char* what) {
-        set_err(err, err_len, std::string("File ") + path + " line " + std::to_string(line_no) + ": " + what);
-        return MVLM_OBJ_ERR_SYNTAX;
+        c->err_line = line_no;
+        c->err_what = what;
     };
     while (p < eof) {
         const char* le = p;
@@ -181,11 +186,9 @@ extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int er
                    is_f = tl == 1 && ts[0] == 'f';
         if (!is_v && !is_vt && !is_f) continue;
         if (is_f) {
-            // faces can have any number of corners
-            ids.clear();
+            // faces can have any number of corners; first pass: count tokens (a face needs three)
             int ntok = 0;
             const char* r = q;
-            // first pass: count tokens (a face needs three)
             while (r < le) {
                 while (r < le && is_space(*r)) ++r;
                 if (r == le) break;
@@ -193,7 +196,7 @@ extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int er
                 ++ntok;
             }
             if (ntok < 3) continue;
-            const long long n_pos = (long long)(pos.size() / 3), n_tex = (long long)(tex.size() / 2);
+            Face f{uint32_t(c->cv.size()), 0u, uint32_t(c->pos.size() / 3), uint32_t(c->tex.size() / 2)};
             r = q;
             while (r < le) {
                 while (r < le && is_space(*r)) ++r;
@@ -203,30 +206,19 @@ extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int er
                 const char* e = r;
                 const char* s1 = s;
                 while (s1 < e && *s1 != '/') ++s1;
-                long long vi = 0, ti = -1;
+                long long vi = 0, ti = NO_TEX;
                 if (!parse_index(s, s1, &vi)) return syntax("bad face index");
-                vi = vi > 0 ? vi - 1 : n_pos + vi;
                 if (s1 < e) {
                     const char* s2 = s1 + 1;
                     const char* e2 = s2;
                     while (e2 < e && *e2 != '/') ++e2;
-                    if (e2 > s2) {
-                        if (!parse_index(s2, e2, &ti)) return syntax("bad face index");
-                        ti = ti > 0 ? ti - 1 : n_tex + ti;
-                    }
+                    if (e2 > s2 && !parse_index(s2, e2, &ti)) return syntax("bad face index");
                 }
-                // the pair as a 64-bit key; indices outside +-2^31 cannot be valid and are rejected below
-                if (vi < -(1ll << 31) || vi >= (1ll << 31)) vi = -(1ll << 31);
-                if (ti < -(1ll << 31) || ti >= (1ll << 31)) ti = ti < 0 ? -(1ll << 31) : (1ll << 31) - 1;
-                const uint64_t key = (uint64_t(uint32_t(int32_t(vi))) << 32) | uint64_t(uint32_t(int32_t(ti)));
-                bool fresh = false;
-                const int32_t id = corners.get(key, int32_t(corner_v.size()), &fresh);
-                if (fresh) { corner_v.push_back(vi); corner_t.push_back(ti); }
-                ids.push_back(id);
+                c->cv.push_back(vi);
+                c->ct.push_back(ti);
             }
-            for (size_t k = 1; k + 1 < ids.size(); ++k) {  // polygon -> fan
-                tris.push_back(ids[0]); tris.push_back(ids[k]); tris.push_back(ids[k + 1]);
-            }
+            f.count = uint32_t(c->cv.size()) - f.first;
+            c->faces.push_back(f);
             continue;
         }
         // "v x y z [w]" / "vt u v [w]"
@@ -243,20 +235,138 @@ extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int er
         double v[3];
         for (int i = 0; i < need; ++i)
             if (!parse_double(tok_s[i], tok_e[i], &v[i])) return syntax("could not convert string to float");
-        std::vector<float>& dst = is_v ? pos : tex;
+        std::vector<float>& dst = is_v ? c->pos : c->tex;
         for (int i = 0; i < need; ++i) dst.push_back(float(v[i]));
     }
-    const int64_t n_pos = int64_t(pos.size() / 3), n_tex = int64_t(tex.size() / 2);
+    c->lines = line_no;
+}
+
+int reader_threads(size_t bytes) {
+    long want = long(bytes / (256u << 10));  // a thread per 256 KB of text, at most 8
+    if (const char* e = getenv("MVLM_OBJ_THREADS")) want = strtol(e, nullptr, 10);
+    const long hw = long(std::thread::hardware_concurrency());
+    if (!getenv("MVLM_OBJ_THREADS") && hw > 0 && want > hw) want = hw;
+    return int(want < 1 ? 1 : want > 8 ? 8 : want);
+}
+
+}  // namespace
+
+extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int err_len) {
+    if (!path || !out) { set_err(err, err_len, "obj_read: bad arguments"); return MVLM_OBJ_ERR_ARGS; }
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err(err, err_len, std::string("File ") + path + " does not exist."); return MVLM_OBJ_ERR_FILE; }
+    std::vector<char> text;
+    {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        text.resize(sz > 0 ? size_t(sz) : 0);
+        const size_t got = text.empty() ? 0 : fread(text.data(), 1, text.size(), f);
+        text.resize(got);
+        fclose(f);
+    }
+    // ---- cut into chunks right behind a line terminator, parse them side by side
+    const int n_chunks = reader_threads(text.size());
+    std::vector<Chunk> chunks{size_t(n_chunks)};
+    {
+        const char* const base = text.data();
+        const char* const eof = base + text.size();
+        const char* cut = base;
+        for (int k = 0; k < n_chunks; ++k) {
+            chunks[size_t(k)].begin = cut;
+            const char* next = k + 1 == n_chunks ? eof : base + text.size() * size_t(k + 1) / size_t(n_chunks);
+            if (next < cut) next = cut;
+            while (next < eof && next > base && next[-1] != '\n' && next[-1] != '\r') ++next;
+            chunks[size_t(k)].end = cut = next;
+        }
+        std::vector<std::thread> workers;
+        for (int k = 1; k < n_chunks; ++k) workers.emplace_back(parse_chunk, &chunks[size_t(k)]);
+        parse_chunk(&chunks[0]);
+        for (auto& w : workers) w.join();
+    }
+    // ---- the first error in file order is the one a sequential parse stops at
+    {
+        long lines_before = 0;
+        for (const Chunk& c : chunks) {
+            if (c.err_line > 0) {
+                set_err(err, err_len, std::string("File ") + path + " line " + std::to_string(lines_before + c.err_line) + ": " + c.err_what);
+                return MVLM_OBJ_ERR_SYNTAX;
+            }
+            lines_before += c.lines;
+        }
+    }
+    // ---- element bases, concatenated positions / texture coordinates
+    std::vector<long long> pos_base(size_t(n_chunks) + 1, 0), tex_base(size_t(n_chunks) + 1, 0);
+    size_t n_corner_refs = 0, n_fan = 0;
+    for (int k = 0; k < n_chunks; ++k) {
+        pos_base[size_t(k) + 1] = pos_base[size_t(k)] + (long long)(chunks[size_t(k)].pos.size() / 3);
+        tex_base[size_t(k) + 1] = tex_base[size_t(k)] + (long long)(chunks[size_t(k)].tex.size() / 2);
+        n_corner_refs += chunks[size_t(k)].cv.size();
+        for (const Face& fc : chunks[size_t(k)].faces) n_fan += fc.count - 2;
+    }
+    const int64_t n_pos = pos_base[size_t(n_chunks)], n_tex = tex_base[size_t(n_chunks)];
     if (n_pos == 0) {
         set_err(err, err_len, std::string("File ") + path + " does not contain any points.");
         return MVLM_OBJ_ERR_EMPTY;
     }
+    std::vector<float> pos(size_t(n_pos) * 3), tex(size_t(n_tex) * 2);
+    for (int k = 0; k < n_chunks; ++k) {
+        const Chunk& c = chunks[size_t(k)];
+        if (!c.pos.empty()) memcpy(&pos[size_t(pos_base[size_t(k)]) * 3], c.pos.data(), c.pos.size() * sizeof(float));
+        if (!c.tex.empty()) memcpy(&tex[size_t(tex_base[size_t(k)]) * 2], c.tex.data(), c.tex.size() * sizeof(float));
+    }
     mvlm_obj* o = new mvlm_obj;
     o->n_positions = n_pos;
-    if (tris.empty()) {  // a point cloud: keep the points, nothing to render or to snap to
+    if (n_fan == 0) {  // a point cloud: keep the points, nothing to render or to snap to
         o->verts.swap(pos);
         *out = o;
         return 0;
+    }
+    // ---- corners (v, vt) numbered in order of first use.  Scans name a point with ONE texture coordinate almost
+    // everywhere: the first pair of a point sits in a table indexed by the point, only further pairs go through the hash map
+    std::vector<long long> corner_v, corner_t;
+    std::vector<long long> first_t(size_t(n_pos), NO_TEX - 1);   // NO_TEX - 1: point not used yet
+    std::vector<int32_t> first_id(size_t(n_pos), 0);
+    CornerMap corners;
+    std::vector<int32_t> tris;
+    std::vector<int32_t> ids;
+    corner_v.reserve(size_t(n_pos) + 16);
+    corner_t.reserve(size_t(n_pos) + 16);
+    tris.reserve(n_fan * 3);
+    (void)n_corner_refs;
+    for (int k = 0; k < n_chunks; ++k) {
+        const Chunk& c = chunks[size_t(k)];
+        for (const Face& fc : c.faces) {
+            const long long seen_pos = pos_base[size_t(k)] + fc.pos_before, seen_tex = tex_base[size_t(k)] + fc.tex_before;
+            ids.clear();
+            for (uint32_t j = fc.first; j < fc.first + fc.count; ++j) {
+                long long vi = c.cv[j], ti = c.ct[j];
+                vi = vi > 0 ? vi - 1 : seen_pos + vi;
+                ti = ti == NO_TEX ? -1 : (ti > 0 ? ti - 1 : seen_tex + ti);
+                // indices outside +-2^31 cannot be valid and are rejected below
+                if (vi < -(1ll << 31) || vi >= (1ll << 31)) vi = -(1ll << 31);
+                if (ti < -(1ll << 31) || ti >= (1ll << 31)) ti = ti < 0 ? -(1ll << 31) : (1ll << 31) - 1;
+                int32_t id;
+                if (vi >= 0 && vi < n_pos && first_t[size_t(vi)] == NO_TEX - 1) {
+                    first_t[size_t(vi)] = ti;
+                    id = first_id[size_t(vi)] = int32_t(corner_v.size());
+                    corner_v.push_back(vi);
+                    corner_t.push_back(ti);
+                } else if (vi >= 0 && vi < n_pos && first_t[size_t(vi)] == ti) {
+                    id = first_id[size_t(vi)];
+                } else {
+                    const uint64_t key = (uint64_t(uint32_t(int32_t(vi))) << 32) | uint64_t(uint32_t(int32_t(ti)));
+                    bool fresh = false;
+                    id = corners.get(key, int32_t(corner_v.size()), &fresh);
+                    if (fresh) { corner_v.push_back(vi); corner_t.push_back(ti); }
+                }
+                ids.push_back(id);
+            }
+            for (size_t q = 1; q + 1 < ids.size(); ++q) {  // polygon -> fan
+                tris.push_back(ids[0]); tris.push_back(ids[q]); tris.push_back(ids[q + 1]);
+            }
+        }
     }
     const size_t nc = corner_v.size();
     o->verts.resize(nc * 3);

@@ -136,6 +136,17 @@ class Pipeline(abc.ABC):
         elif is_active(block):
             raise ValueError("a pre-align block needs a renderer that applies it (HipRenderer3D.pre_align)")
 
+    def _texture_needed(self) -> bool:
+        """Does anything downstream read a texture-shaded plane of the views?  The reference always decodes the JPEG
+        (utils3d.py:26-36) and renders RGB + depth; a depth or geometry(+depth) model then never looks at the colours.
+        Kept: whenever the views are written out (render_image_stack) or go to a predictor whose planes are unknown."""
+        sel = getattr(self.predictor_2d, "chan_sel", None)
+        if self.render_image_stack or sel is None or not isinstance(self.renderer_3d, HipRenderer3D):
+            return True
+        if self.renderer_3d.shading == "geometry":
+            return False  # planes 0..2 carry the build-defined geometry shading
+        return any(int(c) < 3 for c in sel)
+
     def _to_original(self, mesh, landmarks):
         """Landmarks found on a pre-aligned mesh -> the file's own coordinates (utils3d.py:505-527)."""
         m = getattr(mesh, "to_original", None)
@@ -192,6 +203,8 @@ class Pipeline(abc.ABC):
             print(f"File {file_name} does not exist")
             return None
         self._rays = None
+        if hasattr(self.renderer_3d, "needs_texture"):
+            self.renderer_3d.needs_texture = self._texture_needed()
         with self._timer.stage("total"):
             if self._fusable():
                 landmarks = self._predict_fused(file_name)
@@ -446,6 +459,8 @@ class Pipeline(abc.ABC):
         files = [Path(f) for f in files]
         if self.predictor_2d is None:
             raise ValueError("Predictor2D is not initialized.")
+        if hasattr(self.renderer_3d, "needs_texture"):
+            self.renderer_3d.needs_texture = self._texture_needed()
         if not self._fusable() or prefetch <= 0:
             for f in files:
                 yield f, self.predict_one_file(f)

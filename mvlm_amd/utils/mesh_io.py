@@ -88,7 +88,9 @@ def _read_texture(jpg: Path):
         from PIL import Image
 
         with Image.open(jpg) as im:
-            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+            if im.mode != "RGB":
+                im = im.convert("RGB")
+            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))  # one copy out of the decoder's buffer
     except Exception:  # noqa: BLE001 - "if we cannot load the texture, we just ignore it" (utils3d.py:35-36)
         return None
 

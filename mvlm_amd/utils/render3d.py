@@ -114,6 +114,9 @@ class HipRenderer3D:
         # "pre-align" block of a Deep-MVLM config (utils/prealign.py; utils3d.py:465-503): applied to every mesh this
         # renderer loads, the mesh handle it returns carries the matrix (Mesh.to_original)
         self.pre_align: dict | None = None
+        # False: the consumer of the views reads no texture-shaded plane (depth / geometry models), so load_mesh leaves the
+        # JPEG alone - at 2048x2048 its decode (17 ms, single-threaded by format) is 6x the parse of the geometry
+        self.needs_texture = True
         self.ctx = _lib.get_context(device)
 
     # ---- pose table (render3d.py:79-112) ----------------------------------------------
@@ -198,7 +201,7 @@ class HipRenderer3D:
         """OBJ (+ texture) from disk, through the ``pre_align`` block when one is set."""
         from .prealign import aligned
 
-        return aligned(load_obj(file_name), self.pre_align)
+        return aligned(load_obj(file_name, load_texture=self.needs_texture), self.pre_align)
 
     def multiview_render_device(self, file_or_mesh, transformation_stack=None):
         """Same, but the image stack stays in HBM (used by the fused pipeline path)."""

@@ -105,6 +105,30 @@ def test_predict_files_applies_pre_align_once(tmp_path):
         assert np.abs(a).max() < 12.0                      # file coordinates: a scan of +-5 units around (3, -2, 1.5)
 
 
+def test_depth_models_skip_the_texture_decode(tmp_path):
+    """A depth (or geometry) model never reads the colour planes: load_mesh leaves the JPEG alone (17 of 20 ms of a
+    2048x2048-texture scan's ingest) and the landmarks are those of the run that decoded it.  Writing the views out
+    (render_image_stack) or an RGB model brings the texture back."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    obj = write_face_like_obj(tmp_path / "face.obj", grid=40, tex_size=64, seed=1)
+    pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:3", image_mode="depth", verbose=False)
+    np.random.seed(5)
+    lean = pipe.predict_one_file(obj)
+    assert pipe.renderer_3d.needs_texture is False and pipe.renderer_3d.load_mesh(obj).texture is None
+    pipe.render_image_stack, pipe.render_image_folder = True, tmp_path
+    np.random.seed(5)
+    full = pipe.predict_one_file(obj)
+    assert pipe.renderer_3d.needs_texture is True and pipe.renderer_3d.load_mesh(obj).texture is not None
+    np.testing.assert_array_equal(lean, full)
+    rgb = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:3", image_mode="RGB+depth", verbose=False)
+    assert rgb.predict_one_file(obj) is not None and rgb.renderer_3d.needs_texture is True
+    geo = pipeline.create_pipeline("dtu3d", n_views=8, weights="synthetic:3", image_mode="geometry+depth", verbose=False)
+    geo.renderer_3d.shading = "geometry"
+    assert geo.predict_one_file(obj) is not None and geo.renderer_3d.needs_texture is False
+
+
 def test_write_renderings_key_dumps_the_views(tmp_path):
     """process_3d.write_renderings (configs/DTU3D-RGB_Artec3D.json ...) -> general_pipeline.py:133-146's PNG dump."""
     from PIL import Image

@@ -108,6 +108,70 @@ def test_native_obj_reader_equals_python_statement(tmp_path):
         assert m.n_tris == 0 and m.n_verts == 2 and m.uvs is None
 
 
+def test_chunk_parallel_obj_parse_equals_one_thread(tmp_path, monkeypatch):
+    """The native reader cuts the text into one chunk per thread (round 3): for 1, 2, 3, 5 and 8 chunks the mesh is the
+    single-threaded one bit for bit - points, corner numbering in order of first use, negative indices that count back
+    across chunk borders, a point used with several texture coordinates, CR/LF line ends - and a syntax error is
+    reported for the same line."""
+    from mvlm_amd.utils.mesh_io import load_obj
+
+    rs = np.random.RandomState(9)
+    lines, n_v, n_vt = [], 0, 0
+    for block in range(40):                      # points, texture coordinates and faces interleaved through the file
+        for _ in range(rs.randint(3, 30)):
+            lines.append("v %.6f %.6f %.6f" % tuple(rs.standard_normal(3) * 50))
+            n_v += 1
+        for _ in range(rs.randint(0, 20)):
+            lines.append("vt %.5f %.5f" % tuple(rs.rand(2)))
+            n_vt += 1
+        if block % 7 == 3:
+            lines += ["# a comment", "", "g group%d" % block, "vn 0 0 1"]
+        for _ in range(rs.randint(5, 40)):
+            k = rs.randint(3, 6)
+            corners = []
+            for _ in range(k):
+                vi = rs.randint(1, n_v + 1) if rs.rand() < 0.7 else -rs.randint(1, n_v + 1)
+                if n_vt and rs.rand() < 0.8:
+                    ti = rs.randint(1, n_vt + 1) if rs.rand() < 0.7 else -rs.randint(1, n_vt + 1)
+                    corners.append(f"{vi}/{ti}" + ("/1" if rs.rand() < 0.2 else ""))
+                else:
+                    corners.append(str(vi) + ("//1" if rs.rand() < 0.2 else ""))
+            lines.append("f " + " ".join(corners))
+    text = "\n".join(lines[:200]) + "\r\n" + "\r\n".join(lines[200:400]) + "\n" + "\n".join(lines[400:]) + "\n"
+    p = tmp_path / "mixed.obj"
+    p.write_bytes(text.encode())
+    monkeypatch.setenv("MVLM_OBJ_THREADS", "1")
+    one = load_obj(p, reader="native")
+    _same_mesh(one, load_obj(p, reader="python"))
+    assert one.n_tris > 500 and one.uvs is not None
+    for n in (2, 3, 5, 8):
+        monkeypatch.setenv("MVLM_OBJ_THREADS", str(n))
+        _same_mesh(load_obj(p, reader="native"), one)
+    # the first bad line wins, whichever chunk it falls into, with its line number in the whole file
+    bad = lines[:]
+    bad[len(bad) * 2 // 3] = "v 1 oops 3"
+    bad[len(bad) * 5 // 6] = "f 1 2 x"
+    q = tmp_path / "bad.obj"
+    q.write_text("\n".join(bad) + "\n")
+    messages = set()
+    for n in (1, 2, 4, 8):
+        monkeypatch.setenv("MVLM_OBJ_THREADS", str(n))
+        with pytest.raises(ValueError) as e:
+            load_obj(q, reader="native")
+        messages.add(str(e.value))
+    assert len(messages) == 1 and f"line {len(bad) * 2 // 3 + 1}:" in messages.pop()
+    # a big scan takes the threaded path by default
+    monkeypatch.delenv("MVLM_OBJ_THREADS")
+    from mvlm_amd.utils.synthetic import face_like_mesh, write_face_like_obj
+
+    big = write_face_like_obj(tmp_path / "big.obj", grid=120, tex_size=8)
+    assert big.stat().st_size > 1_000_000
+    m, ref = load_obj(big), face_like_mesh(120, 8)
+    monkeypatch.setenv("MVLM_OBJ_THREADS", "1")
+    _same_mesh(m, load_obj(big))
+    assert m.n_tris == ref.n_tris
+
+
 def test_native_obj_reader_rounds_numbers_like_python(tmp_path):
     """Every decimal spelling must land on the same float32 as Python's float() -> np.float32."""
     from mvlm_amd.utils.mesh_io import load_obj

@@ -227,7 +227,7 @@ def test_reader_errors(tmp_path):
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 def test_mesh_readers_under_sanitizers(tmp_path):
     exe = tmp_path / "harness"
-    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
                         "-x", "c++", str(REPO / "mvlm_amd/csrc/mesh_readers.hip"), str(REPO / "mvlm_amd/csrc/obj_reader.hip"),
                         str(REPO / "tests/native/mesh_reader_harness.cpp"), "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -32,3 +32,18 @@ for it in range(4):
 t0 = T()
 for _ in range(5): pipe.predict_one_file(obj)
 print("predict_one_file avg", 1e3*(T()-t0)/5, pipe.timings)
+# the parts of load_obj, and the native reader with 1 thread vs its default (chunk-parallel parse)
+import os
+from mvlm_amd.utils import mesh_io
+def best(fn, n=7):
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+    return 1e3 * min(ts)
+print(f"native OBJ reader, default threads: {best(lambda: mesh_io._read_obj_native(obj)):.2f} ms")
+for n in ("1", "2", "4", "8"):
+    os.environ["MVLM_OBJ_THREADS"] = n
+    print(f"native OBJ reader, {n} thread(s): {best(lambda: mesh_io._read_obj_native(obj)):.2f} ms")
+del os.environ["MVLM_OBJ_THREADS"]
+print(f"JPEG decode (2048x2048): {best(lambda: mesh_io._read_texture(obj.with_suffix('.jpg'))):.2f} ms")
+print(f"load_obj (both, JPEG on a second thread): {best(lambda: load_obj(obj)):.2f} ms")
