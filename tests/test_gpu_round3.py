@@ -58,8 +58,11 @@ def test_pre_align_block_through_predict_one_file(tmp_path, stem, n_views):
     verts, t = opre.pre_transformation(raw.verts, block)
     np.random.seed(4)
     poses = pipe.renderer_3d.generate_3d_transformations()
+    # a depth model's pipeline does not decode the JPEG (nothing reads the colour planes): the oracle renders untextured too
+    texture = raw.texture if pipe.renderer_3d.needs_texture else None
+    assert pipe.renderer_3d.needs_texture == (mode != "depth")
     with contextlib.redirect_stdout(io.StringIO()):
-        want, _, inter = opipe.predict_mesh(verts, raw.tris, raw.uvs, raw.texture, poses,
+        want, _, inter = opipe.predict_mesh(verts, raw.tris, raw.uvs, texture, poses,
                                             weights.synthetic_state_dict(nl, c, seed=9), arch.CHANNEL_SELECT[mode])
     want = opre.landmarks_to_original_space(want, t)
     mesh = pipe.renderer_3d.load_mesh(path)
@@ -127,6 +130,39 @@ def test_depth_models_skip_the_texture_decode(tmp_path):
     geo = pipeline.create_pipeline("dtu3d", n_views=8, weights="synthetic:3", image_mode="geometry+depth", verbose=False)
     geo.renderer_3d.shading = "geometry"
     assert geo.predict_one_file(obj) is not None and geo.renderer_3d.needs_texture is False
+
+
+@pytest.mark.parametrize("name,mode,n_views", [("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)])
+def test_fast_precision_against_the_oracle(name, mode, n_views):
+    """precision="fast" (opt-in bf16x3 arithmetic, never the default, never bench.py's value) against the CPU ORACLE, not
+    just against the exact path: the same render, < 1 % of the argmax planes move (near-ties), and every landmark whose
+    views all picked the oracle's pixel lands within 1e-3 model units.  Full-size figures: profiles/r03_fast_vs_oracle_*."""
+    from mvlm_amd import arch, pipeline, weights
+    from mvlm_amd.utils.synthetic import face_like_mesh
+    from oracle import pipeline as opipe
+
+    pipe = pipeline.create_pipeline(name, n_views=n_views, weights="synthetic:11", verbose=False, image_mode=mode,
+                                    precision="fast")
+    assert pipe.predictor_2d.precision == "fast"
+    mesh = face_like_mesh(60, 128, 11)
+    np.random.seed(0)
+    poses = pipe.renderer_3d.generate_3d_transformations()
+    np.random.seed(1)
+    got, _ = pipe.predict_mesh_device(mesh, poses)
+    gmax = pipe.predictor_2d.predict_device(pipe.renderer_3d.render_device(mesh, poses)).cpu().numpy()
+    nl = pipe.get_lm_count()
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        want, _, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses,
+                                            weights.synthetic_state_dict(nl, arch.IMAGE_CHANNELS[mode], seed=11),
+                                            arch.CHANNEL_SELECT[mode])
+    diff = ~np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)
+    assert diff.mean() <= 0.01
+    same = ~diff.any(axis=1)
+    assert same.mean() > 0.8
+    assert np.abs(got[same] - want[same]).max() < 1e-3
+    scores = np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[~diff]
+    assert scores.max() < 1e-4 * max(1.0, np.abs(inter["maxima"][:, :, 2]).max())
 
 
 def test_write_renderings_key_dumps_the_views(tmp_path):
