@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/README.md cites for one round, in one pass on the GPU box: usage tools/collect_evidence.sh r02
+# Everything profiles/README.md cites for one round, in one pass on the GPU box: usage tools/collect_evidence.sh r03
 # (results under gpurun_out/evidence_<tag>/ with the names they get in profiles/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/evidence_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -12,12 +12,23 @@ timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_n1.
 export MVLM_BENCH_NO_INGEST=1
 echo "== other configs" ; date
 timeout -k 10 300 python3 bench.py --config bu3dfe-depth-8 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_b8views.json 2> $OUT/${TAG}_bench_b8views.stderr.txt || exit 1
-timeout -k 10 300 python3 bench.py --config dtu3d-geomdepth-96 --views-total 12 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_b12views.json 2> $OUT/${TAG}_bench_b12views.stderr.txt || exit 1
 timeout -k 10 300 python3 bench.py --config dtu3d-rgb-64 --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_dtu3d_rgb_64views.json 2> /dev/null || exit 1
 timeout -k 10 300 python3 bench.py --config mediapipe-478x128 --steps 20 --warmup 5 --cpu-views 0 > $OUT/${TAG}_bench_mediapipe_478x128.json 2> /dev/null || exit 1
 echo "== parity reports" ; date
 timeout -k 10 600 python3 tests/reports/parity_stats.py 8 > $OUT/${TAG}_parity_stats.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe > $OUT/${TAG}_e2e_parity_96views.txt 2>&1 || exit 1
+timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe fast RGB+depth > $OUT/${TAG}_fast_vs_oracle_bu3dfe_rgbd_96views.txt 2>&1 || exit 1
+timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 64 224 dtu3d fast RGB > $OUT/${TAG}_fast_vs_oracle_dtu3d_rgb_64views.txt 2>&1 || exit 1
+echo "== ingest segments, per-level tables" ; date
+timeout -k 10 300 python3 tools/ingest_segments.py > $OUT/${TAG}_ingest_segments.txt 2>&1 || exit 1
+for v in 8 12; do
+  MVLM_BENCH_PER_LAYER=1 timeout -k 10 300 python3 bench.py --config dtu3d-geomdepth-96 --views-total $v --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_dtu3d_${v}views.json 2> $OUT/${TAG}_bench_dtu3d_${v}views.stderr.txt || exit 1
+  python3 tools/per_level_table.py $OUT/${TAG}_bench_dtu3d_${v}views.stderr.txt > $OUT/${TAG}_per_level_${v}views.txt
+done
+MVLM_BENCH_PER_LAYER=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > /dev/null 2> $OUT/per_layer_96.err || exit 1
+python3 tools/per_level_table.py $OUT/per_layer_96.err > $OUT/${TAG}_per_level_96views.txt
+echo "== bench.py --gpus 2 as a plain process (two gloo ranks sharing this GPU)" ; date
+MVLM_BENCH_SHARE_GPU=1 timeout -k 10 600 python3 bench.py --gpus 2 --steps 5 --warmup 2 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_rehearsal_self_launch_2ranks_one_gpu_gloo.json 2> $OUT/self_launch.err || exit 1
 echo "== rocprofv3" ; date
 WORKLOAD="bu3dfe-rgbd-96:96v/gpu" timeout -k 10 1200 bash tools/profile_gpu.sh $TAG > $OUT/profile_log.txt 2>&1 || exit 1
 P=$ROOT/gpurun_out/prof_$TAG
