@@ -9,14 +9,20 @@
  *
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; the message is
- *     available from mvlm_last_error(ctx).  Nothing throws across the boundary.
+ *     available from mvlm_last_error(ctx) - the CALLING THREAD's last failure on that
+ *     ctx, valid until that thread's next failing call.  Nothing throws across the boundary.
  *   - "_dev" pointers are device (HBM) addresses owned by the caller (e.g. a torch
  *     tensor's data_ptr()); "_host" pointers are ordinary host memory.  The library
  *     never frees caller memory.
  *   - all work is enqueued on the ctx's HIP stream (mvlm_set_stream; default: the
  *     null stream).  Functions that return host results synchronise that stream.
  *   - a ctx serialises its callers with an internal mutex (the reference server
- *     calls predict_one_file from a thread pool without locks, 3DMD_server.py:26-31).
+ *     calls predict_one_file from a thread pool without locks, 3DMD_server.py:26-31);
+ *     one C call is atomic, a SEQUENCE of calls that shares buffers is the caller's to
+ *     order (the Python Pipeline holds a lock of its own around a whole scan).
+ *     mvlm_mesh_upload may run on other threads beside the launching one: its host work
+ *     happens outside the ctx mutex.  mvlm_obj_read / mvlm_mesh_read need no ctx at all
+ *     (mvlm_obj_read parses on up to 8 threads of its own; MVLM_OBJ_THREADS overrides).
  */
 #ifndef MVLM_HIP_H
 #define MVLM_HIP_H

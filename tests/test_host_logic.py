@@ -1,6 +1,7 @@
 """CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side
 logic (OBJ ingest, configs, weight packing, view sharding) behaves like the reference."""
 import json
+import os
 import re
 from pathlib import Path
 
@@ -580,3 +581,20 @@ def test_host_allocator_hint_is_idempotent_and_optional(monkeypatch):
     assert first in (True, False) and hostmem.retain_freed_host_memory() is first
     a = np.ones(4 << 20, np.uint8)  # allocations keep working either way
     assert int(a.sum()) == 4 << 20
+
+
+def test_bench_parent_refuses_without_enough_gpus():
+    """`python bench.py --gpus N` as a plain process is the launcher of its N ranks; on a machine that shows fewer GPUs
+    it exits non-zero with a clear message, prints nothing on stdout and never touches a GPU (this container has none)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MVLM_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "needs 2 visible GPUs" in r.stderr
