@@ -141,6 +141,7 @@ def _e2e_config(dataset, mode, n_views, grid, seed):
     ("DTU3D", "geometry+depth", 12, 60),      # configs[3]'s per-GPU shard: C = 2, 12 views, geometry shading
     ("BU_3DFE", "RGB+depth", 16, 60),         # configs[2]'s network (C = 4, 84 landmarks)
     ("BU_3DFE", "RGB+depth", 96, 224),        # configs[2] at full size: the configuration bench.py's value is quoted on
+    ("DTU3D", "geometry+depth", 96, 224),     # configs[3] at full size on one GPU (its 8-GPU form shards these 96 views)
 ])
 def test_end_to_end_config_matrix_against_oracle(dataset, mode, n_views, grid):
     got, gerr, want, werr, inter, gmax, unit = _e2e_config(dataset, mode, n_views, grid, 13)
@@ -331,6 +332,14 @@ def test_execution_modes_give_identical_results(n_views):
     pred.set_execution(graphs=False, concurrency=True)
     np.testing.assert_array_equal(pred.predict_device(imgs, out=out).cpu().numpy(), want.cpu().numpy())
     assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
+    # concurrency 2 (round 3): only the small skip blocks (32x32 / 16x16 / 8x8) on the side stream, eager and replayed
+    pred.set_execution(graphs=False, concurrency=2)
+    np.testing.assert_array_equal(pred.predict_device(imgs, out=out).cpu().numpy(), want.cpu().numpy())
+    assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
+    pred.set_execution(graphs=True, concurrency=2)
+    for i in range(4):
+        out.zero_()
+        assert torch.equal(pred.predict_device(imgs, out=out), want), f"concurrency 2, pass {i}"
     pred.set_execution(graphs=True, concurrency=True)
     before = pred.execution_stats()
     for i in range(4):  # 1st: eager, 2nd: capture + launch, then replays
