@@ -122,9 +122,8 @@ int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const
                       float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch);
 /* How the ~160 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
  * shapes is captured as a hipGraph the second time it is seen and replayed afterwards; 0: always launch by
- * launch.  concurrency (batches of <= 32 views only) 1: the lower hourglass pyramid runs on a second stream
- * beside the 128x128 / 64x64 skip blocks; 2: only the skip blocks of the 32x32 / 16x16 / 8x8 levels run there,
- * beside the descent; 0 (default): one stream.  Results are identical in every mode.
+ * launch.  concurrency 1: for batches of <= 32 views the lower hourglass pyramid runs on a second stream
+ * beside the 128x128 / 64x64 skip blocks; 0 (default): one stream.  Results are identical in every mode.
  * mvlm_cnn_execution_stats reports how many passes ran eagerly / were captured / replayed, and how many
  * captures failed (those passes ran eagerly instead). */
 int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency);

@@ -125,14 +125,6 @@ struct Exec {
         if (hipEventRecord(e, ctx->stream) != hipSuccess || hipStreamWaitEvent(st.side_stream, e, 0) != hipSuccess)
             rc = ctx->fail("cnn: fork of the side stream failed");
     }
-    // what the main stream has enqueued so far happens before what the side stream gets from now on (streams already apart)
-    void side_after_main() {
-        if (dry || rc) return;
-        hipEvent_t e = next_event();
-        if (rc) return;
-        if (hipEventRecord(e, ctx->stream) != hipSuccess || hipStreamWaitEvent(st.side_stream, e, 0) != hipSuccess)
-            rc = ctx->fail("cnn: ordering the side stream behind the main stream failed");
-    }
     void side() {
         arena = 1;
         if (!dry) ctx->launch_stream = st.side_stream;
@@ -330,63 +322,9 @@ struct Exec {
         // either wait for a CU the big launch has filled or, where they fit beside it, crawl behind its matrix
         // work - DESIGN.md 4.1).  Large batches fill the chip with every launch; there the order is sequential.
         const bool small_batch = long(B) * 32 * 32 <= CONCURRENT_MAX_PIXELS_32;
-        const bool concurrent = st.concurrency == 1 && small_batch;
+        const bool concurrent = st.concurrency != 0 && small_batch;
         Tensor lowt11, lowt12, lowt13, lowt14;
         Tensor low1 = rb(R(2), x_pooled, nullptr, &lowt11);
-        if (st.concurrency == 2 && small_batch) {
-            // concurrency = 2 (round 3): only SMALL launches share the chip.  The skip blocks of the 32x32, 16x16 and 8x8
-            // levels (up12, up13, up14: nine convolutions nobody needs before the way back up) go to the side stream,
-            // each as soon as its input exists, while the main stream descends through low12 ... low2; the 128x128 / 64x64
-            // blocks stay in sequence.  One join before the first addition (add1 needs up14, the side stream's last block).
-            Tensor up1 = rb(R(1), x, nullptr);
-            Tensor up11 = rb(R(3), low1, nullptr);
-            release(low1);
-            Tensor low11 = rb(R(4), lowt11, nullptr, &lowt12);
-            release(lowt11);
-            fork();
-            side();
-            Tensor up12 = rb(R(5), low11, nullptr);
-            main();
-            release(low11);  // main-arena releases wait for the join while the streams run apart
-            Tensor low12 = rb(R(6), lowt12, nullptr, &lowt13);
-            release(lowt12);
-            side_after_main();
-            side();
-            Tensor up13 = rb(R(7), low12, nullptr);
-            main();
-            release(low12);
-            Tensor low13 = rb(R(8), lowt13, nullptr, &lowt14);
-            release(lowt13);
-            side_after_main();
-            side();
-            Tensor up14 = rb(R(9), low13, nullptr);
-            main();
-            release(low13);
-            Tensor low14 = rb(R(10), lowt14, nullptr);
-            release(lowt14);
-            Tensor low2 = rb(R(11), low14, nullptr);
-            release(low14);
-            join();
-            rb(R(12), low2, &up14);  // add1
-            release(low2);
-            Tensor low21 = rb(R(13), up14, nullptr);
-            release(up14);
-            rb(R(14), low21, &up13);  // add2
-            release(low21);
-            Tensor low22 = rb(R(15), up13, nullptr);
-            release(up13);
-            rb(R(16), low22, &up12);  // add3
-            release(low22);
-            Tensor low23 = rb(R(17), up12, nullptr);
-            release(up12);
-            rb(R(18), low23, &up11);  // add4
-            release(low23);
-            Tensor low24 = rb(R(19), up11, nullptr);
-            release(up11);
-            rb(R(20), low24, &up1);  // add5
-            release(low24);
-            return up1;
-        }
         if (concurrent) {
             fork();
             side();
@@ -788,8 +726,8 @@ extern "C" int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_v
 
 extern "C" int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency) {
     MVLM_ENTER(ctx);
-    MVLM_REQUIRE(ctx, (graph_mode == 0 || graph_mode == 1) && concurrency >= 0 && concurrency <= 2,
-                 "cnn_set_execution: graph_mode 0 / 1, concurrency 0 / 1 / 2");
+    MVLM_REQUIRE(ctx, (graph_mode == 0 || graph_mode == 1) && (concurrency == 0 || concurrency == 1),
+                 "cnn_set_execution: flags must be 0 or 1");
     CnnState& st = ctx->cnn;
     if (concurrency != st.concurrency) {  // captured graphs encode the launch order
         for (auto& g : st.graphs)

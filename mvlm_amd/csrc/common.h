@@ -150,7 +150,7 @@ struct CnnState {
     std::vector<hipEvent_t> sync_events;
     size_t sync_cursor = 0;
     int graph_mode = 1;            // 0: always eager, 1: replay captured graphs when not profiling
-    int concurrency = 0;           // 0: one stream (default); small batches only: 1 lower hourglass pyramid on a side stream, 2 the small skip blocks there
+    int concurrency = 0;           // 0: one stream (default), 1: lower hourglass pyramid on a side stream (small batches)
     // opt-in "fast" precision (conv_fast.hip): bf16x3-split weights of the eligible 3x3 layers, per conv slot
     unsigned short* fast_blob = nullptr;
     std::vector<long long> fast_off;   // u16 element offset per slot, -1 = the layer stays on the exact kernel

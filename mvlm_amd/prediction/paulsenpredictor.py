@@ -270,11 +270,11 @@ class HipPaulsenModel(Predictor2D):
             buf = bufs[name] = torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", holder.ctx.device))
         return buf
 
-    def set_execution(self, graphs: bool = True, concurrency: "bool | int" = False):
+    def set_execution(self, graphs: bool = True, concurrency: bool = False):
         """How the forward pass is issued (mvlm_cnn_set_execution): replayed hipGraphs / launch by launch, and
         whether small batches run the lower hourglass pyramid on a second stream.  Results do not depend on it."""
         for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
-            ctx.check(ctx.lib.mvlm_cnn_set_execution(ctx.handle, int(bool(graphs)), int(concurrency)))
+            ctx.check(ctx.lib.mvlm_cnn_set_execution(ctx.handle, int(bool(graphs)), int(bool(concurrency))))
 
     def execution_stats(self) -> dict:
         v = [C.c_int64() for _ in range(4)]
