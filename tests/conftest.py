@@ -12,8 +12,27 @@ if str(REPO) not in sys.path:
 GOLDEN = REPO / "tests" / "golden"
 
 
+def _host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota (a GPU box shows 256 CPUs and
+    grants 16: torch's default of one thread per visible CPU makes the CPU oracle's network ~8x slower there)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+
+        torch.set_num_threads(_host_cores())
+    except Exception:  # noqa: BLE001
+        pass
 
 
 @pytest.fixture(scope="session")
