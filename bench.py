@@ -525,7 +525,7 @@ def main():
             ingest = ingest_figures(pipe, n_total)
         cpu = None
         n_cpu = min(n_total, 96) if args.cpu_views < 0 else min(args.cpu_views, n_total)
-        if n_cpu > 0 and not fusion_only:
+        if n_cpu > 0 and not fusion_only and world == 1:  # the CPU baseline belongs to the N = 1 line only
             sd = weights.synthetic_state_dict(nl, c, seed=0)
             cpu = cpu_baseline(mesh, poses, sd, arch.CHANNEL_SELECT[cfg.image_channels], n_cpu, n_total,
                                shading="geometry" if "geometry" in cfg.image_channels else "texture")
