@@ -99,13 +99,13 @@ class HipPaulsenModel(Predictor2D):
         MVLM_REPLICA_DEVICES="0,0" names the devices explicitly (rehearsal of the N-device path on one GPU)."""
         import torch
 
-        forced = os.environ.get("MVLM_REPLICA_DEVICES")
-        if forced:
-            ids = [int(v) for v in forced.split(",") if v.strip() != ""]
-            return ids[1:]
         n_gpus = int(n_gpus or 1)
         if n_gpus <= 1:
             return []
+        forced = os.environ.get("MVLM_REPLICA_DEVICES")
+        if forced:
+            ids = [int(v) for v in forced.split(",") if v.strip() != ""]
+            return ids[1:n_gpus]
         have = torch.cuda.device_count()
         if n_gpus > have:
             print(f"Warning: n_gpus={n_gpus} requested, {have} GPU(s) visible - using {have}")
