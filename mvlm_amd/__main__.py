@@ -25,9 +25,13 @@ def main(argv=None) -> int:
     parser = argparse.ArgumentParser(prog="python -m mvlm_amd")
     parser.add_argument("-p", "--path", type=str, required=True)
     parser.add_argument("-o", "--out", type=str, required=False)
-    parser.add_argument("-n", "--n-views", type=int, default=8, help="Number of views to render")
+    parser.add_argument("-n", "--n-views", type=int, default=None, help="Number of views to render (default: 8, or the config's)")
     parser.add_argument("--visualize-method", action="store_true", help="Dump the rendered views as PNG next to the mesh")
     parser.add_argument("--pipelines", type=str, default="bu3dfe,dtu3d")
+    parser.add_argument("-c", "--config", type=str, default=None,
+                        help="a Deep-MVLM JSON config (path, or the stem of one of the reference's configs/*.json, e.g. "
+                             "BU_3DFE-depth): ONE pipeline built from its inference keys - model, image channels, view count "
+                             "(unless -n is given), pose ranges, line filter, pre-align block - instead of --pipelines")
     parser.add_argument("--weights", type=str, default=None,
                         help='checkpoint path, or "synthetic[:seed]" (no checkpoint is reachable offline)')
     parser.add_argument("--device", type=int, default=0)
@@ -71,13 +75,23 @@ def main(argv=None) -> int:
 
     from . import pipeline
 
-    for pname in [p for p in args.pipelines.split(",") if p]:
+    extra = {"precision": "fast"} if args.precision == "fast" else {}
+    if args.config is not None:
+        from . import config as mvlm_config
+
+        src = args.config if Path(args.config).is_file() else mvlm_config.default_config(args.config)
+        jobs = [(Path(args.config).stem, lambda: pipeline.pipeline_from_config(
+            src, n_views=args.n_views, weights=args.weights, device=args.device,
+            **({"render_image_stack": True} if args.visualize_method else {}), **extra))]
+    else:
+        jobs = [(p, (lambda p=p: pipeline.create_pipeline(p, render_image_stack=args.visualize_method, n_views=args.n_views or 8,
+                                                          weights=args.weights, device=args.device, **extra)))
+                for p in args.pipelines.split(",") if p]
+    for pname, make in jobs:
         print(f"Pipeline: {pname}")
         if args.seed is not None:
             np.random.seed(args.seed)
-        dm = pipeline.create_pipeline(pname, render_image_stack=args.visualize_method, n_views=args.n_views,
-                                      weights=args.weights, device=args.device,
-                                      **({"precision": "fast"} if args.precision == "fast" else {}))
+        dm = make()
         # ingest of the next scans overlaps the GPU work
         for file, landmarks in dm.predict_files(obj_files, batch_scans=args.batch_scans):
             print(f"Current file: {file}")

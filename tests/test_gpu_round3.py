@@ -165,6 +165,30 @@ def test_fast_precision_against_the_oracle(name, mode, n_views):
     assert scores.max() < 1e-4 * max(1.0, np.abs(inter["maxima"][:, :, 2]).max())
 
 
+def test_cli_runs_a_config_file(tmp_path):
+    """`python -m mvlm_amd -p folder -c BU_3DFE-depth -n 8`: one pipeline built from the config (here by the stem of the
+    reference's file; a path to a JSON works the same), pre-align block included - the landmark files hold what
+    pipeline_from_config + predict_one_file give."""
+    from mvlm_amd import config
+    from mvlm_amd.__main__ import main
+    from mvlm_amd.pipeline import pipeline_from_config
+
+    cfg = config.default_config("BU_3DFE-depth", n_views=8)
+    files = [_raw_scan(tmp_path, cfg["pre-align"], seed=s, name=f"scan{s}.obj") for s in (1, 2)]
+    out = tmp_path / "out"
+    assert main(["-p", str(tmp_path), "-o", str(out), "-c", "BU_3DFE-depth", "-n", "8", "--weights", "synthetic:9", "--seed", "3"]) == 0
+    pipe = pipeline_from_config(cfg, weights="synthetic:9", verbose=False)
+    np.random.seed(3)
+    for f in files:
+        want = pipe.predict_one_file(f)
+        got = np.loadtxt(out / f"{f.stem}_BU_3DFE-depth.txt", delimiter=",")
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    cfg_path = tmp_path / "my.json"
+    cfg_path.write_text(json.dumps(config.default_config("DTU3D-RGB", n_views=8)))
+    assert main(["-p", str(files[0]), "-o", str(out), "-c", str(cfg_path), "--weights", "synthetic:9"]) == 0
+    assert np.loadtxt(out / "scan1_my.txt", delimiter=",").shape == (73, 3)
+
+
 def test_write_renderings_key_dumps_the_views(tmp_path):
     """process_3d.write_renderings (configs/DTU3D-RGB_Artec3D.json ...) -> general_pipeline.py:133-146's PNG dump."""
     from PIL import Image
