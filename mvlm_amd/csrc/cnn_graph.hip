@@ -464,7 +464,7 @@ struct Exec {
             // carry the four parity slots (2x2 kernels with pre-summed taps) each output parity is
             // one launch over the 128x128 tensor: 16 instead of 36 tap evaluations per low-res pixel.
             const int SLOT_PARITY = SLOT_CONV5 + 6;
-            const bool parity = d(SLOT_PARITY)[0] != 0 && (d(SLOT_PARITY)[5] == 96 || d(SLOT_PARITY)[5] == 80);
+            const bool parity = d(SLOT_PARITY)[0] != 0 && (d(SLOT_PARITY)[5] == 96 || d(SLOT_PARITY)[5] == 80 || d(SLOT_PARITY)[5] == 84);
             const int parts1 = parity ? mvlm_conv_amax_parts(128, 128) : mvlm_conv_amax_parts(256, 256);
             const int parts = parity ? 4 * parts1 : parts1;
             Tensor av, ai;
@@ -681,7 +681,7 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
         if (!r[0]) continue;
         MVLM_REQUIRE(ctx, r[1] > 0 && r[2] > 0 && r[3] >= 1 && r[3] <= 3, "cnn_load: bad conv shape");
         // output channels: multiples of 16 (32-row tiles, 64 + 16-row strip), or exactly 84 = 64 + 16 + 4 rows
-        MVLM_REQUIRE(ctx, r[4] % 4 == 0 && r[4] >= r[1] && (r[5] % 16 == 0 || (r[5] == 84 && r[2] == 84 && r[3] == 3)) && r[5] >= r[2],
+        MVLM_REQUIRE(ctx, r[4] % 4 == 0 && r[4] >= r[1] && (r[5] % 16 == 0 || (r[5] == 84 && r[2] == 84 && (r[3] == 3 || r[3] == 2))) && r[5] >= r[2],
                      "cnn_load: bad padding");
         const size_t wsz = size_t(r[3]) * r[3] * r[4] * r[5];
         MVLM_REQUIRE(ctx, r[6] >= 0 && size_t(r[6]) + wsz <= n_floats, "cnn_load: weight offset out of range");

@@ -52,7 +52,7 @@ struct Cfg {
     static constexpr bool TAIL4 = COUT_T % 32 == 20;
     static constexpr bool TAIL16 = COUT_T % 32 == 16 || TAIL4;
     // the fused argmax serves the last layer only (73 / 84 landmarks -> 80 / 96-row tiles of 8x32 pixels)
-    static constexpr bool HAS_AMAX = NIMG == 1 && TW == 32 && TRI == 8 && KS != 1 && (COUT_T == 80 || COUT_T == 96);
+    static constexpr bool HAS_AMAX = NIMG == 1 && TW == 32 && TRI == 8 && KS != 1 && (COUT_T == 80 || COUT_T == 96 || (COUT_T == 84 && KS == 2));
     static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
     static constexpr int NT16 = TAIL16 ? 2 * NT : 1;  // 16-pixel column groups of a wave
     static constexpr int KSTEPS = TAPS * CKW / 2;
@@ -260,7 +260,8 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
                               : __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16[j], acc16[j], 0, 0, 0);
         }
         if constexpr (C::TAIL4) {
-            static_assert(!C::TAIL4 || !TR, "the 4-row strip has no transposed (fused-argmax) form");
+            // (the strip has one form: with TR the 32-row and 16-row tiles are transposed around it, register v of the
+            //  strip stays channel 32 MT + 16 + v at the lane's pixel)
 #pragma unroll
             for (int c = 0; c < 2; ++c) s4.acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[ks & 1][c], b4[ks & 1][c], s4.acc, 0, 0, 0);
         }
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     if constexpr (C::TAIL4) {
         const int p = wave * (C::PIX_T / 4) + lane;  // this lane's pixel of the tile
         s4.woff4 = C::XT_PAD + C::MT * 32 + 16 + (lane & 3);
-        s4.pixoff4 = (p / C::TW % C::TRI) * C::PW + p % C::TW;
+        s4.pixoff4 = (p / C::TW % C::TRI) * C::PW + p % C::TW + (C::KS == 2 ? a.sub_y * C::PW + a.sub_x : 0);
     }
     // The consumer-side BatchNorm (scale, shift per input channel) is read from an LDS copy.  The first
     // chunk takes its parameters straight from global memory, so the table fill, the first input tile
@@ -680,6 +681,31 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
                 const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + part;
                 a.amax_val[o] = argmax_value(best_k);
                 a.amax_idx[o] = best_i;
+            }
+        }
+        if constexpr (C::TAIL4) {
+            // 4-row strip: register v = channel co0 + 32 MT + 16 + v at THIS lane's pixel (64 consecutive pixels of the
+            // tile per wave): the wave's partial of a channel is a 64-lane reduction, first maximum in row-major order
+            const int p = wave * (C::PIX_T / 4) + lane;
+            const int pix = pixel_index(y0 + p / C::TW, x0 + p % C::TW);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int co = co0 + C::MT * 32 + 16 + v;
+                const float bias = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+                int best_k = argmax_key(s4.acc[v] + bias), best_i = pix;
+#pragma unroll
+                for (int sft = 1; sft <= 32; sft <<= 1) {
+                    const int ok = __shfl_xor(best_k, sft), oi = __shfl_xor(best_i, sft);
+                    if (ok > best_k || (ok == best_k && oi < best_i)) {
+                        best_k = ok;
+                        best_i = oi;
+                    }
+                }
+                if (lane == 0 && co < a.cout && b0 < a.B) {
+                    const size_t o = (size_t(b0) * a.cout + co) * a.amax_parts + part;
+                    a.amax_val[o] = argmax_value(best_k);
+                    a.amax_idx[o] = best_i;
+                }
             }
         }
         return;
@@ -1040,12 +1066,15 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     // ---- the 4-row strip: register v = channel co0 + 32 MT + 16 + v at this lane's pixel (64 consecutive pixels per wave)
     if constexpr (C::TAIL4) {
         const int p = wave * (C::PIX_T / 4) + lane;
-        const unsigned pix = unsigned(y0 + p / C::TW) * unsigned(W) + unsigned(x0 + p % C::TW);
+        const int y = y0 + p / C::TW, x = x0 + p % C::TW;
+        const unsigned pix = a.up_out == 2 ? unsigned(2 * y + a.sub_y) * unsigned(2 * W) + unsigned(2 * x + a.sub_x)
+                                           : unsigned(y) * unsigned(W) + unsigned(x);
+        const unsigned plane = a.up_out == 2 ? 4u * HW : HW;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int co = co0 + C::MT * 32 + 16 + v;
             if (co < a.cout && a.out)
-                a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix] = s4.acc[v] + (a.bias ? a.bias[co] : 0.f);
+                a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * plane + pix] = s4.acc[v] + (a.bias ? a.bias[co] : 0.f);
         }
     }
 
@@ -1069,7 +1098,7 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
     MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
     MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
     MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");
-    if (C::TAIL4) MVLM_REQUIRE(ctx, !a.up_out && !a.amax_val && a.out, "conv: the 84-channel tile writes a plain output tensor");
+    if (C::TAIL4) MVLM_REQUIRE(ctx, a.up_out != 1 && (a.out || (a.amax_val && C::HAS_AMAX)), "conv: the 84-channel tile writes a plain (or parity) output tensor or argmax partials");
     if (C::TAIL16)
         MVLM_REQUIRE(ctx, !a.res1 && !a.res2 && !a.out_raw && !a.post_scale && a.up_out != 1 && !a.pool_out,
                      "conv: the 80-channel tiles serve plain conv + bias layers only");

@@ -51,7 +51,7 @@ constexpr long SPLITK_MAX_PIXELS = 8192;
 
 int pick_variant_rules(const ConvArgs& a) {
     if (a.ksize == 1) return (a.W >= 32 && a.cout_pad % 128 == 0) ? 4 : -1;
-    if (a.ksize == 2) return (a.W >= 32 && a.H % 8 == 0) ? (a.cout_pad == 96 ? 11 : a.cout_pad == 80 ? 17 : -1) : -1;
+    if (a.ksize == 2) return (a.W >= 32 && a.H % 8 == 0) ? (a.cout_pad == 96 ? 11 : a.cout_pad == 80 ? 17 : a.cout_pad == 84 ? 29 : -1) : -1;
     if (a.cout_pad == 80) return (a.W >= 32 && a.H % 8 == 0) ? 16 : -1;  // 64 rows + one 16-row strip
     if (a.cout_pad % 32 == 20)  // 64 + 16 + 4 rows: plain layers writing a plain tensor (conv6 / conv10 of the 84-landmark net)
         return (a.cout_pad == 84 && a.W >= 32 && a.H % 8 == 0 && !a.amax_val && !a.up_out) ? 26 : -1;

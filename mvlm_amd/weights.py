@@ -149,8 +149,10 @@ def pack_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: in
         plain = s.has_bias and s.pre_bn is None and s.post_bn is None  # conv6, conv7, conv10, conv11(+parity)
         if plain and _round_up(s.cout, 16) in COUT_TAIL_PADS:
             cout_pad = _round_up(s.cout, 16)
-        elif plain and s.ksize == 3 and s.cout == COUT_EXACT_84 and s.name in ("conv6", "conv10"):
-            cout_pad = s.cout  # 64 + 16 + 4 rows (conv3x3_c84_t8x32); conv11 keeps 96: its kernels carry the fused argmax
+        elif plain and s.cout == COUT_EXACT_84 and (s.name in ("conv6", "conv10") or s.ksize == 2):
+            # 64 + 16 + 4 rows: conv6 / conv10 (conv3x3_c84_t8x32) and, since round 3, conv11's four parity convolutions
+            # (conv2x2_c84_t8x32, fused argmax on all three row groups); the un-collapsed 3x3 conv11 slot keeps 96
+            cout_pad = s.cout
         row[4:6] = (cin_pad, cout_pad)
         if not s.present:
             continue
