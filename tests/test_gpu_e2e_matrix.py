@@ -401,25 +401,47 @@ def test_heatmap_maxima_nan_and_signed_zero_like_numpy():
     assert np.isnan(want[0, 0, 2]) and want[0, 0, 0] == 4 and want[0, 0, 1] == 6.5 and want[1, 0, 0] == 49
 
 
-def test_fused_argmax_nan_plane_like_numpy():
+@pytest.mark.parametrize("family,nl,poisoned", [("dtu3d", 73, (3, 70)), ("bu3dfe", 84, (3, 70, 81, 83))])
+def test_fused_argmax_nan_plane_like_numpy(family, nl, poisoned):
     """A NaN bias in conv11 makes one landmark's whole heatmap NaN: np.argmax returns pixel 0 and the value NaN
-    (paulsenpredictor.py:123-127); the fused conv11 + argmax kernels must do the same and leave the others alone."""
+    (paulsenpredictor.py:123-127); the fused conv11 + argmax kernels must do the same and leave the others alone.
+    73 landmarks: a channel of the 32-row tiles and one of the 16-row strip; 84 landmarks (conv2x2_c84_t8x32, round 3):
+    also two of the 4-row strip, whose partial maximum is a 64-lane reduction."""
     from conftest import seeded_images
     from mvlm_amd import weights
-    from mvlm_amd.prediction import DTU3DPredictor
+    from mvlm_amd.prediction import BU3DFEPredictor, DTU3DPredictor
 
-    sd = weights.synthetic_state_dict(73, 3, seed=8)
+    cls = DTU3DPredictor if family == "dtu3d" else BU3DFEPredictor
+    sd = weights.synthetic_state_dict(nl, 3, seed=8)
     imgs = dev(seeded_images(31, 3))
-    clean = DTU3DPredictor(image_mode="RGB", weights=sd, verbose=False).predict_device(imgs).cpu().numpy()
+    clean = cls(image_mode="RGB", weights=sd, verbose=False).predict_device(imgs).cpu().numpy()
     sd = dict(sd)
     sd["conv11.bias"] = sd["conv11.bias"].copy()
-    sd["conv11.bias"][[3, 70]] = np.nan          # one channel of the 32-row tiles, one of the 16-row strip
-    got = DTU3DPredictor(image_mode="RGB", weights=sd, verbose=False).predict_device(imgs).cpu().numpy()
-    for lm in (3, 70):
+    sd["conv11.bias"][list(poisoned)] = np.nan
+    got = cls(image_mode="RGB", weights=sd, verbose=False).predict_device(imgs).cpu().numpy()
+    for lm in poisoned:
         np.testing.assert_array_equal(got[lm, :, :2], np.tile(np.float32([-1.0, -0.5]), (3, 1)))
         assert np.isnan(got[lm, :, 2]).all()
-    keep = [i for i in range(73) if i not in (3, 70)]
+    keep = [i for i in range(nl) if i not in poisoned]
     np.testing.assert_array_equal(got[keep], clean[keep])
+
+
+def test_fused_argmax_of_the_four_row_strip_against_the_heatmaps():
+    """conv11 of the 84-landmark network runs on 84 rows (64 + 16 + 4): the fused maxima of EVERY landmark - the last
+    four come out of the 4-row strip's lane reduction - equal the argmax of the materialised heat maps (whose parity
+    stores go through the same tile), first maximum in row-major order, value bit for bit."""
+    from conftest import seeded_images
+    from mvlm_amd.prediction import BU3DFEPredictor
+
+    pred = BU3DFEPredictor(image_mode="RGB+depth", weights="synthetic:21", verbose=False)
+    imgs = dev(seeded_images(77, 5))
+    maxima = pred.predict_device(imgs).cpu().numpy()                     # [84, 5, 3]
+    heat = pred.heatmaps_device(imgs).cpu().numpy()                      # [5, 84, 256, 256]
+    flat = heat.reshape(5, 84, -1)
+    idx = flat.argmax(axis=2)                                            # np.argmax: first maximum
+    np.testing.assert_array_equal(maxima[:, :, 0].T, (idx // 256 - 1).astype(np.float32))
+    np.testing.assert_array_equal(maxima[:, :, 1].T, (idx % 256 - 0.5).astype(np.float32))
+    np.testing.assert_array_equal(maxima[:, :, 2].T, np.take_along_axis(flat, idx[:, :, None], axis=2)[:, :, 0])
 
 
 # ---- every split-K tile variant (32-, 16- and 8-channel chunks) against torch -------------------------------
