@@ -193,7 +193,6 @@ class Pipeline(abc.ABC):
         return (isinstance(self.renderer_3d, HipRenderer3D) and isinstance(self.estimator_3d, HipEstimator3D)
                 and device_predictor)
 
-    @_serialised
     def predict_one_file(self, file_name: Path, landmark_indices: list[int] | None = None,
                          view_indices: list[int] | None = None, clip_rays_to_mesh: bool = True):
         if self.predictor_2d is None:
@@ -202,15 +201,25 @@ class Pipeline(abc.ABC):
         if not file_name.exists():
             print(f"File {file_name} does not exist")
             return None
-        self._rays = None
-        if hasattr(self.renderer_3d, "needs_texture"):
-            self.renderer_3d.needs_texture = self._texture_needed()
-        with self._timer.stage("total"):
-            if self._fusable():
-                landmarks = self._predict_fused(file_name)
-            else:
-                landmarks = self._predict_slots(file_name)
-        self._after_prediction(file_name, landmarks, landmark_indices, view_indices, clip_rays_to_mesh)
+        # File ingest (OBJ parse, JPEG decode: host work, 3-20 ms per scan) runs BEFORE the pipeline lock is taken: the
+        # callers of a server's thread pool (3DMD_server.py:26-31) then parse their scans side by side and only the GPU
+        # section - RNG draws, device buffers, launch graphs, timings - is one caller at a time.
+        mesh, load_seconds = None, 0.0
+        if self._fusable():
+            t0 = time.perf_counter()
+            mesh = self.renderer_3d.load_mesh(self.renderer_3d._check_file(file_name), load_texture=self._texture_needed())
+            load_seconds = time.perf_counter() - t0
+        with self._lock:
+            self._rays = None
+            with self._timer.stage("total"):
+                if mesh is not None:
+                    landmarks = self._predict_fused(file_name, mesh=mesh)
+                else:
+                    landmarks = self._predict_slots(file_name)
+            if mesh is not None:
+                self.timings["load"] = self.timings.get("load", 0.0) + load_seconds
+                self.timings["total"] += load_seconds
+            self._after_prediction(file_name, landmarks, landmark_indices, view_indices, clip_rays_to_mesh)
         return landmarks
 
     def _after_prediction(self, file_name, landmarks, landmark_indices=None, view_indices=None, clip_rays_to_mesh=True):
@@ -459,17 +468,17 @@ class Pipeline(abc.ABC):
         files = [Path(f) for f in files]
         if self.predictor_2d is None:
             raise ValueError("Predictor2D is not initialized.")
-        if hasattr(self.renderer_3d, "needs_texture"):
-            self.renderer_3d.needs_texture = self._texture_needed()
         if not self._fusable() or prefetch <= 0:
             for f in files:
                 yield f, self.predict_one_file(f)
             return
 
+        load_texture = self._texture_needed()
+
         def ingest(f: Path):
             if not f.exists():
                 return None
-            mesh = self.renderer_3d.load_mesh(self.renderer_3d._check_file(f))  # pre-aligned here, uploaded once
+            mesh = self.renderer_3d.load_mesh(self.renderer_3d._check_file(f), load_texture=load_texture)  # pre-aligned here, uploaded once
             if mesh.n_tris > 0:
                 # device copy from the reader thread too: pinned staging + a copy stream of the library's own, so the
                 # transfer runs beside the current scan's kernels (mvlm_mesh_upload); the renderer waits for its event
@@ -494,6 +503,7 @@ class Pipeline(abc.ABC):
                     with self._timer.stage("total"):
                         results = self.predict_meshes_device([m for _, m in group])
                     for (gf, gm), (landmarks, _) in zip(group, results):
+                        self._dump_pre_aligned(gm, gf)  # (ingest pre-aligned the scan)
                         self._rays = None
                         self._after_prediction(gf, landmarks)
                 done = [(gf, landmarks) for (gf, _), (landmarks, _) in zip(group, results)]
@@ -541,7 +551,7 @@ class Pipeline(abc.ABC):
         t0 = time.perf_counter()
         if mesh is None:
             file_name = self.renderer_3d._check_file(file_name)
-            mesh = self.renderer_3d.load_mesh(file_name)
+            mesh = self.renderer_3d.load_mesh(file_name, load_texture=self._texture_needed())
         else:
             mesh = aligned(mesh, self.pre_align)
         sharded = self.shard_views and parallel.is_distributed()
@@ -570,7 +580,10 @@ class Pipeline(abc.ABC):
     def _predict_slots(self, file_name: Path):
         tm = self._timer
         with tm.stage("render"):
-            image_stack, transform_stack, pd = self.renderer_3d.multiview_render(file_name)
+            if isinstance(self.renderer_3d, HipRenderer3D):
+                image_stack, transform_stack, pd = self.renderer_3d.multiview_render(file_name, load_texture=self._texture_needed())
+            else:
+                image_stack, transform_stack, pd = self.renderer_3d.multiview_render(file_name)
         if self.render_image_stack:
             self.visualize_image_stack(image_stack, file_name)
         with tm.stage("prediction"):

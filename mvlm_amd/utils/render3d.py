@@ -114,9 +114,6 @@ class HipRenderer3D:
         # "pre-align" block of a Deep-MVLM config (utils/prealign.py; utils3d.py:465-503): applied to every mesh this
         # renderer loads, the mesh handle it returns carries the matrix (Mesh.to_original)
         self.pre_align: dict | None = None
-        # False: the consumer of the views reads no texture-shaded plane (depth / geometry models), so load_mesh leaves the
-        # JPEG alone - at 2048x2048 its decode (17 ms, single-threaded by format) is 6x the parse of the geometry
-        self.needs_texture = True
         self.ctx = _lib.get_context(device)
 
     # ---- pose table (render3d.py:79-112) ----------------------------------------------
@@ -185,23 +182,27 @@ class HipRenderer3D:
             raise ValueError(f"File {file_name} is not an .obj file. Only .obj files are supported.")
         return file_name
 
-    def multiview_render(self, file_name: Path):
-        """render3d.py:179-193 - numpy results, as the slot contract requires."""
+    def multiview_render(self, file_name: Path, load_texture: bool = True):
+        """render3d.py:179-193 - numpy results, as the slot contract requires.  ``load_texture``: see ``load_mesh``."""
         t = time.time()
         file_name = self._check_file(file_name)
         if self.verbose:
             print("Render [0] - Prepare", f"{time.time() - t:08.6f} s")
         transformation_stack = self.generate_3d_transformations()
-        mesh = self.load_mesh(file_name)
+        mesh = self.load_mesh(file_name, load_texture=load_texture)
         image_stack = self.render_device(mesh, transformation_stack).cpu().numpy()
         self.check()
         return image_stack, transformation_stack, mesh
 
-    def load_mesh(self, file_name: Path) -> Mesh:
-        """OBJ (+ texture) from disk, through the ``pre_align`` block when one is set."""
+    def load_mesh(self, file_name: Path, load_texture: bool = True) -> Mesh:
+        """OBJ (+ texture) from disk, through the ``pre_align`` block when one is set.
+        ``load_texture=False`` leaves the JPEG alone: at 2048x2048 its decode (17 ms, single-threaded by format) is 6x the
+        parse of the geometry, and the consumer of a depth / geometry model's views reads no texture-shaded plane.  It is
+        an argument of the call, decided by the caller that knows the consumer (``Pipeline._texture_needed``) - the
+        renderer keeps no such state, so its public entry points load the texture like the reference (utils3d.py:26-36)."""
         from .prealign import aligned
 
-        return aligned(load_obj(file_name, load_texture=self.needs_texture), self.pre_align)
+        return aligned(load_obj(file_name, load_texture=load_texture), self.pre_align)
 
     def multiview_render_device(self, file_or_mesh, transformation_stack=None):
         """Same, but the image stack stays in HBM (used by the fused pipeline path)."""
