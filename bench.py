@@ -185,23 +185,54 @@ def committed_traffic(workload_key: str, kernel: str):
 
 
 def visible_gpus() -> int:
-    """GPUs a child rank could open, counted WITHOUT initialising the runtime in this process
-    (torch.cuda.device_count() does not open a device on ROCm builds; the parent of the ranks must not)."""
-    import torch
-
-    return int(torch.cuda.device_count())
+    """GPUs a child rank could open, counted from sysfs: no HIP / HSA call, no torch import - this process is the parent of
+    the ranks and must not touch the GPU.  A GPU is a KFD topology node with SIMDs whose render node this process may
+    open (a container sees the host's whole topology but only its own /dev/dri/renderD*); ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow it as they narrow the runtime's list.  Each rank checks again
+    with the runtime itself (authoritative) and exits with the same message when it finds fewer."""
+    root = Path("/sys/class/kfd/kfd/topology/nodes")
+    if not root.is_dir():
+        return 0
+    n = 0
+    for prop in root.glob("*/properties"):
+        try:
+            kv = dict(ln.split()[:2] for ln in prop.read_text().splitlines() if len(ln.split()) >= 2)
+            if int(kv.get("simd_count", "0")) <= 0:
+                continue  # a CPU node
+            minor = int(kv.get("drm_render_minor", "-1"))
+        except (OSError, ValueError):
+            continue  # another container's device: not readable from here
+        node = Path(f"/dev/dri/renderD{minor}")
+        if minor >= 0 and not (node.exists() and os.access(node, os.R_OK | os.W_OK)):
+            continue
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no RANK in the environment (how the driver starts it): start the N ranks
     as fresh child processes - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port <free> bench.py <same arguments>` - relay rank 0's ONE JSON line to stdout, the
-    children's stderr to stderr, and return their exit code.  Nothing here makes a HIP call."""
+    children's stderr to stderr, and return their exit code.  Nothing here makes a HIP call or imports torch: the GPUs are
+    counted from sysfs (visible_gpus)."""
     import socket
     import subprocess
 
     share = os.environ.get("MVLM_BENCH_SHARE_GPU") == "1"
     have = visible_gpus()
+    if have < n and not share:
+        # sysfs may be masked in a container: before refusing, ask the runtime itself - in a throw-away child, so that this
+        # process (the parent of the ranks) still never initialises the GPU
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=600)
+            have = max(have, int(r.stdout.strip().splitlines()[-1]))
+        except Exception:  # noqa: BLE001
+            pass
     if have < n and not share:
         log(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have} "
             f"(MVLM_BENCH_SHARE_GPU=1 rehearses the {n}-rank path with every rank on GPU 0 over gloo)")
@@ -252,6 +283,8 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra pass that measures the opt-in fast precision")
     ap.add_argument("--precision", default="exact", choices=["exact", "fast"], help=argparse.SUPPRESS)  # experiments: time the fast path as the main loop
+    ap.add_argument("--selection", default="simple", choices=["simple", "moment"],
+                    help="heatmap maxima (paulsenpredictor.py:112-158): the argmax pixel (default) or the 31x31 centroid around it - both fused")
     ap.add_argument("--cnn-execution", default="", help=argparse.SUPPRESS)  # "graphs,concurrency" for experiments, e.g. "1,0"
     ap.add_argument("--cpu-views", type=int, default=-1, help="views in the CPU-baseline sample (-1 = the whole workload, at most 96; 0 = skip)")
     args = ap.parse_args()
@@ -268,7 +301,7 @@ def main():
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if world > 1 and os.environ.get("MVLM_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < world:
-        log(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPUs")
+        log(f"bench.py: --gpus {world} needs {world} visible GPUs, the runtime shows {torch.cuda.device_count()}")
         sys.exit(2)
     # MVLM_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single GPU (gloo, every rank on
     # device 0); the real run is one rank per GPU over RCCL ("nccl" backend on ROCm)
@@ -353,6 +386,8 @@ def main():
     if args.cnn_execution and not fusion_only:
         g, cc = (int(v) for v in args.cnn_execution.split(","))
         pipe.predictor_2d.set_execution(graphs=bool(g), concurrency=cc)
+    if args.selection != "simple" and not fusion_only:
+        pipe.predictor_2d.selection_method = args.selection
     if args.precision == "fast" and not fusion_only:
         pipe.predictor_2d.set_precision("fast")
         args.no_fast_mode = True
@@ -411,12 +446,44 @@ def main():
     elapsed = time.perf_counter() - t0
     if not profile_in_timed and rank == 0:
         set_profiling(1)
+    if sharded:
+        parallel.enable_timing(True)  # the all-gather and the draws broadcast of the steps below, per rank
     if not profile_in_timed:
         for _ in range(args.steps):  # every rank joins (collectives inside a step), rank 0 records
             step()
             if rank == 0:
                 collect()
     set_profiling(0)
+    collectives = parallel.timing_summary() if sharded else None
+    if sharded:
+        parallel.enable_timing(False)
+    # the same shard WITHOUT the sharded path (no collectives, this rank draws for itself), timed on rank 0 while the other
+    # ranks wait: what one GPU needs for its 1/N of the views, so that a reader of the JSON line can split the scaling
+    # efficiency into "smaller batch per GPU" (single_gpu_shard_ms x N against the N = 1 step) and "cost of sharding"
+    # (this rank's ms_per_step against single_gpu_shard_ms)
+    single_gpu_shard_ms = None
+    if sharded and world > 1:
+        barrier()
+        if rank == 0 and hi > lo:
+            pipe.shard_views = False
+            try:
+                def shard_step():
+                    np.random.seed(1)
+                    return pipe.predict_mesh_device(mesh, poses[lo:hi])
+
+                if fusion_only:
+                    pred_state["lo"] = lo
+                for _ in range(3):
+                    shard_step()
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    shard_step()
+                torch.cuda.synchronize()
+                single_gpu_shard_ms = 1e3 * (time.perf_counter() - ts) / args.steps
+            finally:
+                pipe.shard_views = True
+        barrier()
     render_ms, render_calls = render_ms[0], render_calls[0]
     exec_stats = None if fusion_only else pipe.predictor_2d.execution_stats()
 
@@ -472,10 +539,13 @@ def main():
                      "max_landmark_deviation_vs_exact_model_units": round(float(np.abs(lm_fast - lm_exact).max()), 6),
                      "fast_kernel_launches_per_step": fk[2] if fk else 0,
                      "fast_kernel_fp32_equivalent_tflops": round(fk[0] / (fk[1] * 1e-3) / 1e12, 1) if fk else None}
+    per_rank_ms = None
     if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        per_rank_ms = [1e3 * float(v.item()) / args.steps for v in every]
+        elapsed = max(float(v.item()) for v in every)  # the job is done when the slowest rank is
 
     if rank == 0:
         views_per_s = n_total * args.steps / elapsed
@@ -553,7 +623,7 @@ def main():
             "config": {"workload": f"{what}: {n_total} views @ 256x256 of one {mesh.n_tris}-triangle textured synthetic "
                                    f"face OBJ, {nl} landmarks" + ("" if fusion_only else f", {c} input channels ({spec['mode']}), seeded random weights"),
                        "name": args.config, "views_total": n_total, "views_per_gpu": per_gpu, "landmarks": nl,
-                       "in_channels": c, "triangles": mesh.n_tris,
+                       "in_channels": c, "triangles": mesh.n_tris, "selection_method": args.selection,
                        "live_conv_gflop_per_view": round(flops_view / 1e9, 2),
                        "parallelism": f"views sharded {per_gpu}/GPU x {world} ({args.scaling} scaling; backend {backend}), "
                                       "1 all-gather of maxima + 1 broadcast of RANSAC draws per mesh" if sharded
@@ -562,6 +632,18 @@ def main():
             "roofline_rasteriser": roof_r,
             "kernel_events": "HIP events live over the timed steps" if profile_in_timed else
                              "HIP events over the same number of steps run right after the timed region (timed steps = product path, replayed launch graphs)",
+            "scaling_breakdown": None if not sharded else {
+                "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3),
+                                         "all": [round(v, 3) for v in per_rank_ms]},
+                "all_gather_ms_per_step": None if collectives["all_gather"]["mean_ms"] is None else round(collectives["all_gather"]["mean_ms"], 4),
+                "draws_broadcast_ms_per_step": None if collectives["broadcast"]["mean_ms"] is None else round(collectives["broadcast"]["mean_ms"], 4),
+                "collective_clock": collectives["all_gather"]["clock"],
+                "single_gpu_shard_ms": None if single_gpu_shard_ms is None else round(single_gpu_shard_ms, 3),
+                "shard_views": hi - lo,
+                "how_to_read": "rank 0's figures.  single_gpu_shard_ms = this rank's shard run unsharded right after the timed region "
+                               "(no process-group traffic): x n_gpus against the N = 1 line's ms_per_step = what the smaller batch per GPU "
+                               "costs; ms_per_step against single_gpu_shard_ms = what sharding costs (the two collectives, measured "
+                               "over the same number of extra steps, + rank skew = max - min of per_rank_ms_per_step)"},
             "cnn_execution": exec_stats,
             "fast_mode": fast_mode,
             "cpu_baseline": cpu,

@@ -116,17 +116,30 @@ size_t mvlm_cnn_workspace_bytes(mvlm_ctx* ctx, int batch);
  * (paulsenpredictor.py:123-127).  Views are processed `batch` at a time. */
 int mvlm_cnn_maxima(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
                     float* maxima_dev, void* workspace_dev, size_t workspace_bytes, int batch);
+/* which maximum mvlm_cnn_maxima reports per (view, landmark) plane (paulsenpredictor.py:112-158): MVLM_MAXIMA_SIMPLE
+ * (default) the argmax pixel, MVLM_MAXIMA_MOMENT the 31x31 centroid around it where the peak lies more than 15 pixels
+ * from every border.  Both come out of the fused path - the heatmaps are never written: for "moment" the window around
+ * each peak is recomputed from conv10's output with conv11's own arithmetic (bit for bit what mvlm_cnn_heatmaps +
+ * mvlm_heatmap_maxima(method 1) give).  Fails when the packed weights carry conv11 without its parity slots. */
+int mvlm_cnn_set_selection(mvlm_ctx* ctx, int method);
 /* same network, but materialises the final-stage heatmaps f32[N,NL,256,256]
- * (what paulsenpredictor.py:187-212 accumulates); used by tests and "moment" mode. */
+ * (what paulsenpredictor.py:187-212 accumulates); used by tests and diagnostics. */
 int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
                       float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch);
-/* How the ~160 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
+/* How the ~155 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
  * shapes is captured as a hipGraph the second time it is seen and replayed afterwards; 0: always launch by
- * launch.  concurrency 1: for batches of <= 32 views the lower hourglass pyramid runs on a second stream
- * beside the 128x128 / 64x64 skip blocks; 0 (default): one stream.  Results are identical in every mode.
+ * launch.  concurrency: 0 (default, the supported mode) = one stream.  1 = EXPERIMENT ONLY: for batches of <= 32 views
+ * the lower hourglass pyramid goes to a second stream beside the 128x128 / 64x64 skip blocks - measured 2-10 % SLOWER
+ * on the MI355X and kept for that measurement, not for use.  Results are identical in every mode.
+ * mvlm_cnn_set_pairing: independent residual blocks of a hourglass level (the skip block and the first block of the
+ * next lower level, paulsenpredictor.py:301-361) share launches conv by conv - 0 never, 1 (default) where the measured
+ * table (csrc/conv_pair_tuned.h) says one two-problem launch beats two launches, 2 wherever one kernel variant can
+ * serve both (tests, tuning).  Per convolution the arithmetic is that of the kernel variant that runs it; a pair may
+ * run another variant than the single launch would, so results can differ in the last bits between pairing modes.
  * mvlm_cnn_execution_stats reports how many passes ran eagerly / were captured / replayed, and how many
  * captures failed (those passes ran eagerly instead). */
 int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurrency);
+int mvlm_cnn_set_pairing(mvlm_ctx* ctx, int mode);
 int mvlm_cnn_execution_stats(mvlm_ctx* ctx, int64_t* eager_runs, int64_t* graph_captures, int64_t* graph_replays,
                              int64_t* graph_failures);
 /* OPT-IN reduced-cost arithmetic ("fast" precision, mvlm_amd/csrc/conv_fast.hip): the big 3x3 layers (input channels a
@@ -164,6 +177,14 @@ int mvlm_conv2d(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, in
                 const float* post_scale_host, const float* post_shift_host, const float* r_dev, int upsample_in,
                 float* y_dev);
 
+/* test hook for the two-problem launch: x_i f32[B,cin,size_i,size_i] * w_i f32[cout,cin,3,3] (shared pre-BN+ReLU per
+ * input channel, optional residual r_i and raw copy raw_i, both f32[B,cout,size_i,size_i]) -> y_i, both in ONE grid of
+ * kernel variant (variant & 255) with 1 << ((variant >> 8) & 3) / 1 << ((variant >> 10) & 3) K parts.  The results equal
+ * mvlm_conv2d's with that variant forced, bit for bit. */
+int mvlm_conv2d_pair(mvlm_ctx* ctx, int batch, int cin, int cout, const float* x0_dev, int size0, const float* w0_host,
+                     const float* r0_dev, float* raw0_dev, float* y0_dev, const float* x1_dev, int size1,
+                     const float* w1_host, const float* r1_dev, float* raw1_dev, float* y1_dev,
+                     const float* pre_scale_host, const float* pre_shift_host, int variant);
 /* test hook: mvlm_conv2d on this ctx runs kernel variant `variant` (ids of mvlm_conv_variant_name; -1 = automatic) */
 int mvlm_conv_force_variant(mvlm_ctx* ctx, int variant);
 /* kernel-variant timing for tools/tune_conv.py: `iters` launches of one layer shape on zero data with kernel
@@ -171,6 +192,11 @@ int mvlm_conv_force_variant(mvlm_ctx* ctx, int variant);
  * add + raw copy, 4 bias, 8 post-BN+ReLU.  Fails for shapes the variant cannot serve. */
 int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int ksize, int size, int flags, int variant, int iters,
                     float* ms_per_launch, int* variant_used);
+/* the same for tools/tune_conv_pairs.py: the 3x3 layer at `size` and at size / 2 (conv j of two independent residual
+ * blocks) as the two tuned single launches (variant < 0) or as ONE two-problem launch of kernel variant (variant & 255)
+ * with 1 << ((variant >> 8) & 3) and 1 << ((variant >> 10) & 3) K parts for the two problems. */
+int mvlm_conv_pair_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int size, int flags, int variant, int iters,
+                         float* ms_per_launch);
 
 /* ---- rays + consensus (replaces estimator3d.py:31-90, :92-183, utils3d.py:99-124) - */
 /* maxima_dev f32[NL,N,3], rot_dev f64[N,9] -> starts_dev, ends_dev f64[NL,N,3] */

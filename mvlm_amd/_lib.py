@@ -49,6 +49,8 @@ SIGNATURES = {
     "mvlm_cnn_heatmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.c_int]),
     "mvlm_cnn_set_execution": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mvlm_cnn_set_selection": (C.c_int, [C.c_void_p, C.c_int]),
+    "mvlm_cnn_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_cnn_execution_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int64)]),
     "mvlm_pack_fast_weights": (C.c_size_t, [c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16)]),
@@ -62,9 +64,13 @@ SIGNATURES = {
     "mvlm_heatmap_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mvlm_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int,
                               c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvlm_conv2d_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, c_float_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int, c_float_p, C.c_void_p, C.c_void_p, C.c_void_p, c_float_p, c_float_p,
+                                   C.c_int]),
     "mvlm_conv_force_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_conv_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   c_float_p, C.POINTER(C.c_int)]),
+    "mvlm_conv_pair_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p]),
     "mvlm_estimate_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p]),
     "mvlm_consensus_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,

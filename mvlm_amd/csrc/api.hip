@@ -401,3 +401,137 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
     if (variant_used) *variant_used = used;
     return rc;
 }
+
+// ---- two independent 3x3 convolutions in one launch (test hook for conv_pair_kernel) -----------------------------------
+// Problem i: x_i f32[B,cin,size_i,size_i] * w_i f32[cout,cin,3,3] (+ shared pre-BN+ReLU, + residual r_i, raw copy raw_i)
+// -> y_i; `variant` as in mvlm_conv_pair_bench.  The results must equal mvlm_conv2d's with the same kernel variant forced.
+extern "C" int mvlm_conv2d_pair(mvlm_ctx* ctx, int batch, int cin, int cout, const float* x0_dev, int size0, const float* w0_host,
+                                const float* r0_dev, float* raw0_dev, float* y0_dev, const float* x1_dev, int size1,
+                                const float* w1_host, const float* r1_dev, float* raw1_dev, float* y1_dev,
+                                const float* pre_scale_host, const float* pre_shift_host, int variant) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, x0_dev && x1_dev && w0_host && w1_host && y0_dev && y1_dev && variant >= 0, "conv2d_pair: bad arguments");
+    MVLM_REQUIRE(ctx, (pre_scale_host == nullptr) == (pre_shift_host == nullptr), "conv2d_pair: pre scale/shift come in pairs");
+    const int cin_pad = (cin + 3) / 4 * 4, cout_pad = (cout + 31) / 32 * 32;
+    const size_t n_w = (size_t(9) * cin_pad * cout_pad + 3) / 4 * 4;
+    std::vector<float> blob(2 * n_w + 2 * size_t(cin_pad), 0.f);
+    const float* ws[2] = {w0_host, w1_host};
+    for (int i = 0; i < 2; ++i)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t) blob[i * n_w + (size_t(t) * cin_pad + ci) * cout_pad + co] = ws[i][(size_t(co) * cin + ci) * 9 + t];
+    if (pre_scale_host)
+        for (int i = 0; i < cin; ++i) {
+            blob[2 * n_w + i] = pre_scale_host[i];
+            blob[2 * n_w + cin_pad + i] = pre_shift_host[i];
+        }
+    auto* d = static_cast<float*>(ctx->get_scratch("conv2d.blob", blob.size() * 4));
+    MVLM_REQUIRE(ctx, d, "conv2d_pair: scratch allocation failed");
+    MVLM_CHECK_HIP(ctx, hipMemcpy(d, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs a[2];
+    const float* xs[2] = {x0_dev, x1_dev};
+    const float* rs[2] = {r0_dev, r1_dev};
+    float* raws[2] = {raw0_dev, raw1_dev};
+    float* ys[2] = {y0_dev, y1_dev};
+    const int sizes[2] = {size0, size1};
+    for (int i = 0; i < 2; ++i) {
+        ConvArgs& c = a[i];
+        c.in = xs[i];
+        c.in_ctot = cin;
+        c.cin = cin;
+        c.cin_pad = cin_pad;
+        c.B = batch;
+        c.H = c.W = sizes[i];
+        c.w = d + i * n_w;
+        c.cout = cout;
+        c.cout_pad = cout_pad;
+        c.ksize = 3;
+        if (pre_scale_host) {
+            c.pre_scale = d + 2 * n_w;
+            c.pre_shift = d + 2 * n_w + cin_pad;
+        }
+        c.res1 = rs[i];
+        c.res1_ctot = cout;
+        c.out_raw = raws[i];
+        c.raw_ctot = cout;
+        c.out = ys[i];
+        c.out_ctot = cout;
+    }
+    if (mvlm_launch_conv_pair(ctx, a[0], a[1], (variant & 0xfff) | MVLM_CONV_PAIR_FLAG)) return 1;
+    MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Tuning hook for tools/tune_conv_pairs.py: conv j of a hourglass level's skip block at `size` and of the next level's first
+// block at size / 2 (same channels, pre-BN + residual + raw copy as in the network) on zero data.  variant < 0: the two
+// tuned single launches back to back; variant >= 0: ONE two-problem launch of kernel variant (variant & 255) with
+// 1 << ((variant >> 8) & 3) / 1 << ((variant >> 10) & 3) K parts for the size / size / 2 problem.
+extern "C" int mvlm_conv_pair_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int size, int flags, int variant, int iters,
+                                    float* ms_per_launch) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, batch > 0 && cin > 0 && cout > 0 && size >= 8 && size % 2 == 0 && iters > 0 && ms_per_launch, "conv_pair_bench: bad arguments");
+    const int cin_pad = (cin + 3) / 4 * 4, cout_pad = (cout + 31) / 32 * 32;
+    const size_t n_w = size_t(9) * cin_pad * cout_pad, n_vec = (size_t(cin_pad) * 2 + size_t(cout_pad) * 3 + 3) / 4 * 4;
+    size_t px[2] = {size_t(batch) * size * size, size_t(batch) * (size / 2) * (size / 2)};
+    size_t total = n_w + n_vec + 64;
+    for (int i = 0; i < 2; ++i) total += (px[i] * cin + 3) / 4 * 4 + 3 * ((px[i] * cout + 3) / 4 * 4);
+    auto* base = static_cast<float*>(ctx->get_scratch("conv_bench", total * sizeof(float)));
+    MVLM_REQUIRE(ctx, base, "conv_pair_bench: scratch allocation failed");
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(base, 0, total * sizeof(float), ctx->stream));
+    float* w = base;
+    float* vec = w + n_w;
+    float* cur = vec + n_vec;
+    ConvArgs a[2];
+    for (int i = 0; i < 2; ++i) {
+        ConvArgs& c = a[i];
+        const size_t n_x = (px[i] * cin + 3) / 4 * 4, n_y = (px[i] * cout + 3) / 4 * 4;
+        c.in = cur;
+        float* y = cur + n_x;
+        float* raw = y + n_y;
+        float* res = raw + n_y;
+        cur = res + n_y;
+        c.in_ctot = cin;
+        c.cin = cin;
+        c.cin_pad = cin_pad;
+        c.B = batch;
+        c.H = c.W = i ? size / 2 : size;
+        c.w = w;
+        c.cout = cout;
+        c.cout_pad = cout_pad;
+        c.ksize = 3;
+        if (flags & 1) {
+            c.pre_scale = vec;
+            c.pre_shift = vec + cin_pad;
+        }
+        if (flags & 2) {
+            c.res1 = res;
+            c.res1_ctot = cout;
+            c.out_raw = raw;
+            c.raw_ctot = cout;
+        }
+        c.out = y;
+        c.out_ctot = cout;
+    }
+    const int saved = ctx->conv_force_variant;
+    ctx->conv_force_variant = -1;
+    auto launch = [&]() -> int {
+        if (variant < 0) return mvlm_launch_conv(ctx, a[0], nullptr) || mvlm_launch_conv(ctx, a[1], nullptr);
+        return mvlm_launch_conv_pair(ctx, a[0], a[1], (variant & 0xfff) | MVLM_CONV_PAIR_FLAG);
+    };
+    int rc = launch();  // warm-up (also sets the launch attributes)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = ctx->fail("conv_pair_bench: hipEventCreate failed");
+    if (!rc) {
+        hipEventRecord(e0, ctx->stream);
+        for (int i = 0; i < iters && !rc; ++i) rc = launch();
+        hipEventRecord(e1, ctx->stream);
+        if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = ctx->fail("conv_pair_bench: kernel failed");
+        float ms = 0.f;
+        if (!rc) hipEventElapsedTime(&ms, e0, e1);
+        *ms_per_launch = ms / iters;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    ctx->conv_force_variant = saved;
+    return rc;
+}

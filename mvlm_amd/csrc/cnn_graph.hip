@@ -152,8 +152,8 @@ struct Exec {
     const int32_t* d(int slot) const { return &st.desc[size_t(slot) * MVLM_CONV_DESC_INTS]; }
     const float* blob(int off) const { return off < 0 ? nullptr : st.blob + off; }
 
-    // fill weights / BN / bias of `slot` into `a` and launch
-    int conv(int slot, const Tensor& x, ConvArgs a, int S) {
+    // weights / BN / bias / shape of `slot` into `a`
+    int fill(int slot, const Tensor& x, ConvArgs& a, int S) {
         if (rc) return rc;
         const int32_t* r = d(slot);
         if (!r[0]) return rc = ctx->fail("cnn: conv slot not present in the packed weights");
@@ -174,24 +174,35 @@ struct Exec {
         a.B = B;
         a.H = a.W = S;
         if (x.C != a.cin) return rc = ctx->fail("cnn: channel mismatch between graph and packed weights");
+        return 0;
+    }
+    bool runs_fast(int slot, const ConvArgs& a) const {
+        return st.fast && size_t(slot) < st.fast_off.size() && st.fast_off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a);
+    }
+    // per-launch HIP events (profiling runs only)
+    int prof_begin(hipEvent_t& e0, hipEvent_t& e1) {
+        if (!st.profiling) return 0;
+        if (st.event_cursor + 2 > st.event_pool.size()) st.event_pool.resize(st.event_cursor + 2, nullptr);
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t& e = st.event_pool[st.event_cursor + k];
+            if (!e && hipEventCreate(&e) != hipSuccess) return rc = ctx->fail("cnn: hipEventCreate failed");
+        }
+        e0 = st.event_pool[st.event_cursor];
+        e1 = st.event_pool[st.event_cursor + 1];
+        st.event_cursor += 2;
+        hipEventRecord(e0, ctx->cur_stream());
+        return 0;
+    }
+    static double conv_flops(const ConvArgs& a) { return 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(a.H) * a.W * a.B * a.n_par; }
+
+    // fill weights / BN / bias of `slot` into `a` and launch
+    int conv(int slot, const Tensor& x, ConvArgs a, int S) {
+        if (fill(slot, x, a, S)) return rc;
         if (dry) return 0;
         int variant = -1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (st.profiling) {
-            if (st.event_cursor + 2 > st.event_pool.size()) {
-                st.event_pool.resize(st.event_cursor + 2, nullptr);
-            }
-            for (int k = 0; k < 2; ++k) {
-                hipEvent_t& e = st.event_pool[st.event_cursor + k];
-                if (!e && hipEventCreate(&e) != hipSuccess) return rc = ctx->fail("cnn: hipEventCreate failed");
-            }
-            e0 = st.event_pool[st.event_cursor];
-            e1 = st.event_pool[st.event_cursor + 1];
-            st.event_cursor += 2;
-            hipEventRecord(e0, ctx->cur_stream());
-        }
-        const bool fast = st.fast && size_t(slot) < st.fast_off.size() && st.fast_off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a);
-        if (fast) {
+        if (prof_begin(e0, e1)) return rc;
+        if (runs_fast(slot, a)) {
             variant = MVLM_CONV_VARIANT_FAST;
             if (mvlm_launch_conv_fast(ctx, a, st.fast_blob + st.fast_off[size_t(slot)])) return rc = 1;
         } else if (mvlm_launch_conv(ctx, a, &variant)) {
@@ -199,87 +210,156 @@ struct Exec {
         }
         if (st.profiling) {
             hipEventRecord(e1, ctx->cur_stream());
-            const double flops = 2.0 * a.cin * a.cout * a.ksize * a.ksize * double(S) * S * B * a.n_par;
-            st.prof.push_back({slot, variant, flops, e0, e1});
+            st.prof.push_back({slot, variant, conv_flops(a), e0, e1});
         }
         return 0;
     }
 
-    // One pre-activation residual block (paulsenpredictor.py:267-273).
-    // hi == nullptr : returns y [cout@S]
+    // the shared launch of two independent convolutions (conv_mfma.hip: mvlm_conv_pair_variant), or -1
+    int pair_variant(int slot0, const Tensor& x0, ConvArgs a0, int S0, int slot1, const Tensor& x1, ConvArgs a1, int S1) {
+        if (st.pairing == 0 || fill(slot0, x0, a0, S0) || fill(slot1, x1, a1, S1)) return -1;
+        if (runs_fast(slot0, a0) || runs_fast(slot1, a1)) return -1;
+        return mvlm_conv_pair_variant(a0, a1, st.pairing);
+    }
+
+    // two independent convolutions: one grid when `pv` names a shared kernel variant, else one launch each
+    int conv_pair(int pv, int slot0, const Tensor& x0, ConvArgs a0, int S0, int slot1, const Tensor& x1, ConvArgs a1, int S1) {
+        if (pv < 0) {
+            conv(slot0, x0, a0, S0);
+            return conv(slot1, x1, a1, S1);
+        }
+        if (fill(slot0, x0, a0, S0) || fill(slot1, x1, a1, S1)) return rc;
+        if (dry) return 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof_begin(e0, e1)) return rc;
+        if (mvlm_launch_conv_pair(ctx, a0, a1, pv)) return rc = 1;
+        if (st.profiling) {
+            hipEventRecord(e1, ctx->cur_stream());
+            st.prof.push_back({slot0, pv, conv_flops(a0) + conv_flops(a1), e0, e1});  // one record: both problems' work, the first one's slot
+        }
+        return 0;
+    }
+
+    // One pre-activation residual block (paulsenpredictor.py:267-273), planned (tensors allocated, launch arguments of
+    // its convolutions filled in) and then issued - alone (rb) or conv by conv beside an independent block (rb_pair).
+    // hi == nullptr : y [cout@S]
     // hi != nullptr : writes upsample2x(y) + *hi into *hi in place ([cout@2S], the hourglass
-    //                 skip tensor), returns an empty tensor
-    // pooled != nullptr : additionally returns max_pool2d(y, 2, 2) in *pooled - fused into the three
+    //                 skip tensor), y stays empty
+    // pooled != nullptr : additionally max_pool2d(y, 2, 2) in *pooled - fused into the three
     //                 convs' epilogues when their kernel variants support it, else by the pool
     //                 kernel; with keep_full == false the full-resolution y is then never written
     //                 (it is still allocated: a resampling block keeps its 1x1 output there)
-    Tensor rb(int rb_index, const Tensor& x, Tensor* hi, Tensor* pooled = nullptr, bool keep_full = true) {
-        const int base = 1 + 4 * rb_index;
-        const int S = x.S;
-        const int cout = d(base + 1)[2] * 2;
-        const int h = cout / 2, q = cout / 4;
-        const bool resample = d(base)[0] != 0;
-        Tensor y;
-        if (!hi) y = alloc(cout, S);
-        const Tensor* res = &x;
-        if (resample) {
-            if (hi) {
-                rc = ctx->fail("cnn: resampling block cannot scatter");
-                return y;
-            }
-            ConvArgs a;
-            a.out = y.p;
-            a.out_ctot = cout;
-            conv(base, x, a, S);
-            res = &y;
+    struct RbPlan {
+        int base = 0, S = 0, cout = 0;
+        bool resample = false;
+        Tensor x, y, t1, t2;
+        Tensor* pooled = nullptr;
+        ConvArgs ar, a[3];   // the 1x1 resample (when present), conv1..conv3
+        const Tensor* in[3] = {nullptr, nullptr, nullptr};
+        bool want_pool = false, keep_full = true;
+    };
+    RbPlan plan_rb(int rb_index, const Tensor& x, Tensor* hi, Tensor* pooled = nullptr, bool keep_full = true) {
+        RbPlan P;
+        P.base = 1 + 4 * rb_index;
+        P.S = x.S;
+        P.x = x;
+        P.cout = d(P.base + 1)[2] * 2;
+        const int cout = P.cout, h = cout / 2, q = cout / 4;
+        P.resample = d(P.base)[0] != 0;
+        if (!hi) P.y = alloc(cout, P.S);
+        if (P.resample && hi) {
+            rc = ctx->fail("cnn: resampling block cannot scatter");
+            return P;
         }
-        auto common = [&](ConvArgs& a, int coff) {
-            a.res1 = res->p;
-            a.res1_ctot = res->C;
-            a.res1_coff = coff;
+        P.t1 = alloc(h, P.S);
+        P.t2 = alloc(q, P.S);
+        if (P.resample) {
+            P.ar.out = P.y.p;
+            P.ar.out_ctot = cout;
+        }
+        const Tensor& res = P.resample ? P.y : P.x;
+        const int coffs[3] = {0, h, h + q};
+        for (int j = 0; j < 3; ++j) {
+            ConvArgs& a = P.a[j];
+            a.res1 = res.p;
+            a.res1_ctot = res.C;
+            a.res1_coff = coffs[j];
             if (hi) {
                 a.out = hi->p;
                 a.out_ctot = hi->C;
-                a.out_coff = coff;
+                a.out_coff = coffs[j];
                 a.up_out = 1;
                 a.skip = hi->p;
                 a.skip_ctot = hi->C;
-                a.skip_coff = coff;
+                a.skip_coff = coffs[j];
             } else {
-                a.out = y.p;
+                a.out = P.y.p;
                 a.out_ctot = cout;
-                a.out_coff = coff;
-            }
-        };
-        Tensor t1 = alloc(h, S), t2 = alloc(q, S);
-        ConvArgs a1, a2, a3;
-        a1.out_raw = t1.p;
-        a1.raw_ctot = h;
-        common(a1, 0);
-        a2.out_raw = t2.p;
-        a2.raw_ctot = q;
-        common(a2, h);
-        common(a3, h + q);
-        bool fused_pool = false;
-        if (pooled && !hi) {
-            *pooled = alloc(cout, S / 2);
-            fused_pool = pool_fusable(base + 1, x, a1, S) && pool_fusable(base + 2, t1, a2, S) && pool_fusable(base + 3, t2, a3, S);
-            if (fused_pool) {
-                for (ConvArgs* a : {&a1, &a2, &a3}) {
-                    a->pool_out = pooled->p;
-                    a->pool_ctot = cout;
-                    a->pool_coff = a->out_coff;
-                    if (!keep_full) a->out = nullptr;
-                }
+                a.out_coff = coffs[j];
             }
         }
-        conv(base + 1, x, a1, S);
-        conv(base + 2, t1, a2, S);
-        conv(base + 3, t2, a3, S);
-        release(t1);
-        release(t2);
-        if (pooled && !hi && !fused_pool && !dry && !rc && mvlm_launch_maxpool2(ctx, y.p, B * cout, S, S, pooled->p)) rc = 1;
-        return y;
+        P.a[0].out_raw = P.t1.p;
+        P.a[0].raw_ctot = h;
+        P.a[1].out_raw = P.t2.p;
+        P.a[1].raw_ctot = q;
+        P.want_pool = pooled && !hi;
+        P.keep_full = keep_full;
+        P.pooled = pooled;
+        if (P.want_pool) *pooled = alloc(cout, P.S / 2);
+        return P;
+    }
+    const Tensor& rb_input(const RbPlan& P, int j) const { return j == 0 ? P.x : (j == 1 ? P.t1 : P.t2); }
+    // the pooled tensor comes out of the three convolutions' epilogues (can_fuse: every one of their kernel variants can) ...
+    void set_pool(RbPlan& P, bool can_fuse) {
+        if (!P.want_pool || !can_fuse) return;
+        for (ConvArgs& a : P.a) {
+            a.pool_out = P.pooled->p;
+            a.pool_ctot = P.cout;
+            a.pool_coff = a.out_coff;
+            if (!P.keep_full) a.out = nullptr;
+        }
+    }
+    // ... or out of the pool kernel behind the block
+    void finish_rb(RbPlan& P) {
+        release(P.t1);
+        release(P.t2);
+        if (P.want_pool && !P.a[0].pool_out && !dry && !rc && mvlm_launch_maxpool2(ctx, P.y.p, B * P.cout, P.S, P.S, P.pooled->p)) rc = 1;
+    }
+
+    Tensor rb(int rb_index, const Tensor& x, Tensor* hi, Tensor* pooled = nullptr, bool keep_full = true) {
+        RbPlan P = plan_rb(rb_index, x, hi, pooled, keep_full);
+        if (rc) return P.y;
+        if (P.resample) conv(P.base, x, P.ar, P.S);
+        bool fuse = P.want_pool;
+        for (int j = 0; j < 3 && fuse; ++j) fuse = pool_fusable(P.base + 1 + j, rb_input(P, j), P.a[j], P.S);
+        set_pool(P, fuse);
+        for (int j = 0; j < 3; ++j) conv(P.base + 1 + j, rb_input(P, j), P.a[j], P.S);
+        finish_rb(P);
+        return P.y;
+    }
+
+    // Two residual blocks that do not depend on each other (a hourglass level's skip block and the first block of the
+    // next lower level, paulsenpredictor.py:301-361): conv j of both in ONE launch wherever a shared kernel variant is known
+    // to be faster than two launches (st.pairing; the measured table conv_pair_tuned.h), else conv by conv as usual.
+    // yA = rb(rbA, xA), yB = rb(rbB, xB) with its pooled copy in *pooledB.
+    void rb_pair(int rbA, const Tensor& xA, Tensor& yA, int rbB, const Tensor& xB, Tensor& yB, Tensor* pooledB) {
+        RbPlan PA = plan_rb(rbA, xA, nullptr), PB = plan_rb(rbB, xB, nullptr, pooledB);
+        yA = PA.y;
+        yB = PB.y;
+        if (rc) return;
+        if (PA.resample) conv(PA.base, xA, PA.ar, PA.S);
+        if (PB.resample) conv(PB.base, xB, PB.ar, PB.S);
+        int pv[3];
+        bool fuse = PB.want_pool;
+        for (int j = 0; j < 3; ++j) {
+            pv[j] = pair_variant(PA.base + 1 + j, rb_input(PA, j), PA.a[j], PA.S, PB.base + 1 + j, rb_input(PB, j), PB.a[j], PB.S);
+            if (fuse) fuse = pv[j] >= 0 ? mvlm_conv_variant_can_pool(pv[j]) : pool_fusable(PB.base + 1 + j, rb_input(PB, j), PB.a[j], PB.S);
+        }
+        set_pool(PB, fuse);
+        for (int j = 0; j < 3; ++j)
+            conv_pair(pv[j], PA.base + 1 + j, rb_input(PA, j), PA.a[j], PA.S, PB.base + 1 + j, rb_input(PB, j), PB.a[j], PB.S);
+        finish_rb(PA);
+        finish_rb(PB);
     }
 
     // the four parity slots of conv11 differ in their weights only (same shapes, one bias): they can share a launch
@@ -324,31 +404,42 @@ struct Exec {
         const bool small_batch = long(B) * 32 * 32 <= CONCURRENT_MAX_PIXELS_32;
         const bool concurrent = st.concurrency != 0 && small_batch;
         Tensor lowt11, lowt12, lowt13, lowt14;
-        Tensor low1 = rb(R(2), x_pooled, nullptr, &lowt11);
-        if (concurrent) {
+        Tensor up1, up11, up12, up13, up14, low1, low11, low12, low13, low14;
+        if (!concurrent) {
+            // way down: at every level the skip block (up1*) and the first block of the next lower level (low1*) read the
+            // same tensor / its pooled copy and do not depend on each other - issued as pairs (rb_pair)
+            rb_pair(R(1), x, up1, R(2), x_pooled, low1, &lowt11);
+            rb_pair(R(3), low1, up11, R(4), lowt11, low11, &lowt12);
+            release(low1);
+            release(lowt11);
+            rb_pair(R(5), low11, up12, R(6), lowt12, low12, &lowt13);
+            release(low11);
+            release(lowt12);
+            rb_pair(R(7), low12, up13, R(8), lowt13, low13, &lowt14);
+            release(low12);
+            release(lowt13);
+            rb_pair(R(9), low13, up14, R(10), lowt14, low14, nullptr);
+            release(low13);
+            release(lowt14);
+        } else {
+            low1 = rb(R(2), x_pooled, nullptr, &lowt11);
             fork();
             side();
+            low11 = rb(R(4), lowt11, nullptr, &lowt12);
+            release(lowt11);
+            up12 = rb(R(5), low11, nullptr);
+            release(low11);
+            low12 = rb(R(6), lowt12, nullptr, &lowt13);
+            release(lowt12);
+            up13 = rb(R(7), low12, nullptr);
+            release(low12);
+            low13 = rb(R(8), lowt13, nullptr, &lowt14);
+            release(lowt13);
+            up14 = rb(R(9), low13, nullptr);
+            release(low13);
+            low14 = rb(R(10), lowt14, nullptr);
+            release(lowt14);
         }
-        Tensor up1, up11;
-        if (!concurrent) {
-            up1 = rb(R(1), x, nullptr);
-            up11 = rb(R(3), low1, nullptr);
-            release(low1);
-        }
-        Tensor low11 = rb(R(4), lowt11, nullptr, &lowt12);
-        release(lowt11);
-        Tensor up12 = rb(R(5), low11, nullptr);
-        release(low11);
-        Tensor low12 = rb(R(6), lowt12, nullptr, &lowt13);
-        release(lowt12);
-        Tensor up13 = rb(R(7), low12, nullptr);
-        release(low12);
-        Tensor low13 = rb(R(8), lowt13, nullptr, &lowt14);
-        release(lowt13);
-        Tensor up14 = rb(R(9), low13, nullptr);
-        release(low13);
-        Tensor low14 = rb(R(10), lowt14, nullptr);
-        release(lowt14);
         Tensor low2 = rb(R(11), low14, nullptr);
         release(low14);
         rb(R(12), low2, &up14);  // add1 = up(low3) + up14, in place in up14
@@ -467,10 +558,13 @@ struct Exec {
             const bool parity = d(SLOT_PARITY)[0] != 0 && (d(SLOT_PARITY)[5] == 96 || d(SLOT_PARITY)[5] == 80 || d(SLOT_PARITY)[5] == 84);
             const int parts1 = parity ? mvlm_conv_amax_parts(128, 128) : mvlm_conv_amax_parts(256, 256);
             const int parts = parity ? 4 * parts1 : parts1;
-            Tensor av, ai;
+            Tensor av, ai, abest;
+            const bool moment = !heat && st.selection == 1;
+            if (moment && !parity) return rc = ctx->fail("cnn: the fused moment selection needs conv11 in its parity form");
             if (!heat) {
                 av = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
                 ai = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
+                if (moment) abest = alloc_raw(size_t(B) * NL * 4, 0, 0);
             }
             // the four parities share their input tiles: ONE launch with the parities of a tile on neighbouring workgroups
             // (ConvArgs::n_par); MVLM_CONV11_PARITY_LAUNCHES=4 keeps one launch per parity (experiments)
@@ -506,10 +600,21 @@ struct Exec {
             if (!heat) {
                 if (!dry && !rc &&
                     mvlm_launch_amax_final(ctx, av.p, reinterpret_cast<int*>(ai.p), B, view0, n_total, NL, parts, 256,
-                                           maxima))
+                                           maxima, moment ? reinterpret_cast<int*>(abest.p) : nullptr))
                     rc = 1;
+                if (moment && !dry && !rc) {
+                    // paulsenpredictor.py:129-156 on the planes whose peak lies more than 15 pixels inside: the 31x31 window is
+                    // recomputed from x10 with the parity kernels' own arithmetic - no [N,NL,256,256] tensor
+                    const int32_t* r0 = d(SLOT_PARITY);
+                    const float* wq[4];
+                    for (int q = 0; q < 4; ++q) wq[q] = blob(d(SLOT_PARITY + q)[6]);
+                    if (mvlm_launch_moment_refine(ctx, x10.p, B, NL, r0[4], r0[5], wq, blob(r0[7]), reinterpret_cast<int*>(abest.p), view0,
+                                                  n_total, maxima))
+                        rc = 1;
+                }
                 release(av);
                 release(ai);
+                if (moment) release(abest);
             }
         }
         release(x10);
@@ -736,6 +841,39 @@ extern "C" int mvlm_cnn_set_execution(mvlm_ctx* ctx, int graph_mode, int concurr
     }
     st.graph_mode = graph_mode;
     st.concurrency = concurrency;
+    return 0;
+}
+
+extern "C" int mvlm_cnn_set_selection(mvlm_ctx* ctx, int method) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, method == MVLM_MAXIMA_SIMPLE || method == MVLM_MAXIMA_MOMENT, "cnn_set_selection: 0 simple, 1 moment");
+    CnnState& st = ctx->cnn;
+    MVLM_REQUIRE(ctx, st.loaded, "cnn_set_selection: mvlm_cnn_load comes first");
+    if (method == MVLM_MAXIMA_MOMENT) {
+        const int slot = 1 + 4 * 43 + 6;
+        const int32_t* r = &st.desc[size_t(slot) * MVLM_CONV_DESC_INTS];
+        MVLM_REQUIRE(ctx, r[0] != 0 && (r[5] == 96 || r[5] == 80 || r[5] == 84) && r[3] == 2,
+                     "cnn_set_selection: the fused moment selection needs conv11's parity slots in the packed weights");
+    }
+    if (method != st.selection) {  // captured graphs encode the launches
+        for (auto& g : st.graphs)
+            if (g.exec) hipGraphExecDestroy(g.exec);
+        st.graphs.clear();
+    }
+    st.selection = method;
+    return 0;
+}
+
+extern "C" int mvlm_cnn_set_pairing(mvlm_ctx* ctx, int mode) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, mode >= 0 && mode <= 2, "cnn_set_pairing: 0 never, 1 the measured table (default), 2 wherever one kernel variant serves both");
+    CnnState& st = ctx->cnn;
+    if (mode != st.pairing) {  // captured graphs encode the launches
+        for (auto& g : st.graphs)
+            if (g.exec) hipGraphExecDestroy(g.exec);
+        st.graphs.clear();
+    }
+    st.pairing = mode;
     return 0;
 }
 

@@ -151,6 +151,9 @@ struct CnnState {
     size_t sync_cursor = 0;
     int graph_mode = 1;            // 0: always eager, 1: replay captured graphs when not profiling
     int concurrency = 0;           // 0: one stream (default), 1: lower hourglass pyramid on a side stream (small batches)
+    int selection = 0;             // heatmap maxima of mvlm_cnn_maxima: 0 "simple" (argmax pixel), 1 "moment" (31x31 centroid around it)
+    int pairing = 1;               // independent residual blocks of a hourglass level share launches: 0 never, 1 where the measured
+                                   // table says so (default), 2 wherever one kernel variant can serve both (tests, tuning)
     // opt-in "fast" precision (conv_fast.hip): bf16x3-split weights of the eligible 3x3 layers, per conv slot
     unsigned short* fast_blob = nullptr;
     std::vector<long long> fast_off;   // u16 element offset per slot, -1 = the layer stays on the exact kernel
@@ -266,6 +269,11 @@ constexpr long MVLM_KPARTS_MAX_PARTS = 4096;  // tiles x parts (4 KB of partial 
 int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt);
 int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
 bool mvlm_conv_can_pool(const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
+bool mvlm_conv_variant_can_pool(int variant);
+// two independent convolutions in one grid (conv_kernel.h: conv_pair_kernel)
+constexpr int MVLM_CONV_PAIR_FLAG = 0x1000;  // variant code of a paired launch: flag | base id | lg(kparts0) << 8 | lg(kparts1) << 10
+int mvlm_conv_pair_variant(const ConvArgs& a0, const ConvArgs& a1, int mode);
+int mvlm_launch_conv_pair(mvlm_ctx* ctx, const ConvArgs& a0, const ConvArgs& a1, int pair_variant);
 int mvlm_conv_amax_parts(int H, int W);  // partials per (image, channel) the argmax epilogue writes
 const char* mvlm_conv_variant_name_impl(int v);
 
@@ -285,4 +293,7 @@ constexpr int MVLM_CONV_VARIANT_FAST = 62;  // id reported for launches of the b
 int mvlm_launch_pack_input(mvlm_ctx* ctx, const float* images, int n, const int* sel4, int c, float* out);
 int mvlm_launch_maxpool2(mvlm_ctx* ctx, const float* in, int planes, int H, int W, float* out);
 int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int n_img, int view0, int n_views_total,
-                           int nl, int parts, int size, float* maxima);
+                           int nl, int parts, int size, float* maxima, int* best_idx = nullptr);
+// "moment" refinement of the fused argmax's peaks from conv10's output (misc.hip: moment_refine_kernel)
+int mvlm_launch_moment_refine(mvlm_ctx* ctx, const float* x10, int n_img, int nl, int cin_pad, int cout_pad, const float* const w_par[4],
+                              const float* bias, const int* best_idx, int view0, int n_views_total, float* maxima);

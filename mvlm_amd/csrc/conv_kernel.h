@@ -66,6 +66,8 @@ struct Cfg {
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
+    // variants that also exist as a two-problem launch (conv_pair_kernel): the tiles of the residual blocks' 3x3 convolutions
+    static constexpr bool PAIRABLE = KS == 3 && COUT_T % 32 == 0 && COUT_T != 96;
     static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
                   "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
     static_assert(!TAIL4 || PIX_T == 256, "the 4-row strip gives every lane of a wave one pixel: 64 pixels per wave");
@@ -276,9 +278,13 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
 //   in flight into registers; after the MFMAs they get their BatchNorm+ReLU and are written to
 //   the other stage; ONE barrier per chunk.  The kernel may use the whole 512-register file
 //   (launch bounds 256,1), so nothing spills and the 128 accumulators stay in registers.
+//
+// conv_tile is the whole workgroup program; the kernels below only say which problem a workgroup belongs to:
+// conv_mfma_kernel = one convolution per launch (block `bid` of `nblk`), conv_pair_kernel = two independent convolutions
+// of the same tile configuration in one grid.
 template <class C, bool AMAX>
-__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a_in, const int tiles_x, const int tiles_y,
-                                                           const int cout_tiles) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_x, const int tiles_y, const int cout_tiles,
+                                          const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -291,7 +297,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     // XCD a contiguous run of tiles (cout tiles of one pixel tile share its input in L2).
     int lid;
     {
-        const int nblk = gridDim.x, bid = blockIdx.x;
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -1080,15 +1085,43 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
 
 }
 
-// ---- variant table ---------------------------------------------------------------------
-// id, name, instantiation.  W >= 32 uses row-segment tiles; smaller levels fold rows /
-// images into the 32-pixel MFMA column.
+template <class C, bool AMAX>
+__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a_in, const int tiles_x, const int tiles_y,
+                                                           const int cout_tiles) {
+    conv_tile<C, AMAX>(a_in, tiles_x, tiles_y, cout_tiles, int(blockIdx.x), int(gridDim.x));
+}
+
+// Two independent convolutions in ONE grid (same tile configuration; e.g. conv j of a hourglass level's skip block and
+// conv j of the block that starts the next lower level - paulsenpredictor.py:301-361, up1 = rb(x) beside low1 =
+// rb(pool(x))): workgroups [0, nblk[0]) belong to problem 0, [nblk0_pad, gridDim.x) to problem 1 (nblk0_pad = nblk[0] rounded
+// up to a multiple of 8, so that blockIdx & 7 is the XCD in both ranges; the workgroups between exit).  A latency-bound
+// launch of a small level then rides in the tail of the larger one without any cross-queue dependency, and the pair pays
+// one grid fill and drain instead of two.  Results are those of the two separate launches with this variant, bit for bit.
+struct ConvPairArgs {
+    ConvArgs a[2];
+    int tiles_x[2], tiles_y[2], cout_tiles[2], nblk[2];
+    int nblk0_pad;
+};
+
 template <class C>
-int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
-    ConvArgs a = a_in;
-#if defined(MVLM_CONV_TIMING)  // diagnostic build: the tool passes its counter buffer through the environment
-    if (const char* e = getenv("MVLM_CONV_TIMING_BUF")) a.timing = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
-#endif
+__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_pair_kernel(const ConvPairArgs p) {
+    const int bid = int(blockIdx.x);
+    const int which = bid >= p.nblk0_pad ? 1 : 0;
+    if (!which && bid >= p.nblk[0]) return;
+    conv_tile<C, false>(p.a[which], p.tiles_x[which], p.tiles_y[which], p.cout_tiles[which], which ? bid - p.nblk0_pad : bid,
+                        p.nblk[which]);
+}
+
+// ---- launchers -------------------------------------------------------------------------
+struct ConvGrid {
+    int tiles_x = 0, tiles_y = 0, cout_tiles = 0;
+    long tiles = 0;  // output tiles (x parities); the grid has tiles * kparts workgroups
+    long nblk = 0;
+};
+
+// host-side checks of one problem against a variant's tile geometry; fills the grid
+template <class C>
+int check_variant(mvlm_ctx* ctx, ConvArgs& a, ConvGrid& g) {
     const int tiles_x = a.W / C::TW, tiles_y = a.H / C::TRI;
     const int tiles_b = (a.B + C::NIMG - 1) / C::NIMG;
     const int cout_tiles = a.cout_pad / C::COUT_T;
@@ -1120,36 +1153,107 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
     }
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv: bad grid");
     a.kparts = a.kparts > 1 ? a.kparts : 1;
+    g.tiles = nblk;
     if (a.kparts > 1) {
         MVLM_REQUIRE(ctx, C::SPLITK, "conv: only the split-K tiles divide the input channels over workgroups");
         MVLM_REQUIRE(ctx, a.cin_pad % (a.kparts * C::CK) == 0, "conv: input channels do not divide into the requested K parts");
-        MVLM_REQUIRE(ctx, nblk <= MVLM_KPARTS_MAX_TILES && nblk * a.kparts <= MVLM_KPARTS_MAX_PARTS, "conv: too many tiles for the K-part workspace");
-        if (mvlm_conv_kparts_workspace(ctx, &a.kws, &a.kcnt)) return 1;
         nblk *= a.kparts;
     }
-    // dynamic-LDS limit of this variant's kernels: set once per context, i.e. per device (hipFuncSetAttribute
-    // applies to the current device's copy of the function; the ctx mutex held by every entry point guards the mask)
-    if (!((ctx->conv_attr_mask >> variant_id) & 1ull)) {
-        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
+    MVLM_REQUIRE(ctx, nblk < (1l << 31), "conv: bad grid");
+    g.tiles_x = tiles_x;
+    g.tiles_y = tiles_y;
+    g.cout_tiles = cout_tiles;
+    g.nblk = nblk;
+    return 0;
+}
+
+// dynamic-LDS limit of this variant's kernels: set once per context, i.e. per device (hipFuncSetAttribute
+// applies to the current device's copy of the function; the ctx mutex held by every entry point guards the mask)
+template <class C>
+int set_variant_attributes(mvlm_ctx* ctx, int variant_id) {
+    if ((ctx->conv_attr_mask >> variant_id) & 1ull) return 0;
+    MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+    if constexpr (C::HAS_AMAX)
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
-        if constexpr (C::HAS_AMAX)
-            MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, true>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
-        ctx->conv_attr_mask |= 1ull << variant_id;
+    if constexpr (C::PAIRABLE)
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<C>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+    ctx->conv_attr_mask |= 1ull << variant_id;
+    return 0;
+}
+
+template <class C>
+int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
+    ConvArgs a = a_in;
+#if defined(MVLM_CONV_TIMING)  // diagnostic build: the tool passes its counter buffer through the environment
+    if (const char* e = getenv("MVLM_CONV_TIMING_BUF")) a.timing = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
+    ConvGrid g;
+    if (check_variant<C>(ctx, a, g)) return 1;
+    if (a.kparts > 1) {
+        MVLM_REQUIRE(ctx, g.tiles <= MVLM_KPARTS_MAX_TILES && g.nblk <= MVLM_KPARTS_MAX_PARTS, "conv: too many tiles for the K-part workspace");
+        if (mvlm_conv_kparts_workspace(ctx, &a.kws, &a.kcnt)) return 1;
     }
+    if (set_variant_attributes<C>(ctx, variant_id)) return 1;
     if (a.amax_val) {
         if constexpr (C::HAS_AMAX) {
-            hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(),
-                               a, tiles_x, tiles_y, cout_tiles);
+            hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)g.nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(),
+                               a, g.tiles_x, g.tiles_y, g.cout_tiles);
         } else {
             return ctx->fail("conv: fused argmax is only built for the 8x32-pixel tile variants");
         }
     } else {
-        hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
-                           tiles_x, tiles_y, cout_tiles);
+        hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)g.nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
+                           g.tiles_x, g.tiles_y, g.cout_tiles);
     }
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
+}
+
+// two independent convolutions on this variant's tiles in one grid (conv_pair_kernel); kparts of each problem in its ConvArgs
+template <class C>
+int launch_variant_pair(mvlm_ctx* ctx, const ConvArgs& a0, const ConvArgs& a1, int variant_id) {
+    if constexpr (!C::PAIRABLE) {
+        return ctx->fail("conv: this kernel variant has no two-problem form");
+    } else {
+        ConvPairArgs p;
+        p.a[0] = a0;
+        p.a[1] = a1;
+        ConvGrid g[2];
+        for (int i = 0; i < 2; ++i) {
+            ConvArgs& a = p.a[i];
+            MVLM_REQUIRE(ctx, !a.amax_val && a.n_par == 1 && !a.timing, "conv: a paired launch takes plain convolutions");
+            if (check_variant<C>(ctx, a, g[i])) return 1;
+        }
+        if (p.a[0].kparts > 1 || p.a[1].kparts > 1) {
+            // one workspace per launch stream: problem 1's partial tiles and counters follow problem 0's
+            const long t0 = p.a[0].kparts > 1 ? g[0].tiles : 0, n0 = p.a[0].kparts > 1 ? g[0].nblk : 0;
+            const long t1 = p.a[1].kparts > 1 ? g[1].tiles : 0, n1 = p.a[1].kparts > 1 ? g[1].nblk : 0;
+            MVLM_REQUIRE(ctx, t0 + t1 <= MVLM_KPARTS_MAX_TILES && n0 + n1 <= MVLM_KPARTS_MAX_PARTS, "conv: too many tiles for the K-part workspace");
+            float* kws = nullptr;
+            unsigned* kcnt = nullptr;
+            if (mvlm_conv_kparts_workspace(ctx, &kws, &kcnt)) return 1;
+            p.a[0].kws = kws;
+            p.a[0].kcnt = kcnt;
+            p.a[1].kws = kws + size_t(n0) * 1024;
+            p.a[1].kcnt = kcnt + t0;
+        }
+        for (int i = 0; i < 2; ++i) {
+            p.tiles_x[i] = g[i].tiles_x;
+            p.tiles_y[i] = g[i].tiles_y;
+            p.cout_tiles[i] = g[i].cout_tiles;
+            p.nblk[i] = int(g[i].nblk);
+        }
+        p.nblk0_pad = (p.nblk[0] + 7) / 8 * 8;
+        const long total = long(p.nblk0_pad) + p.nblk[1];
+        MVLM_REQUIRE(ctx, total < (1l << 31), "conv: bad grid");
+        if (set_variant_attributes<C>(ctx, variant_id)) return 1;
+        hipLaunchKernelGGL((conv_pair_kernel<C>), dim3((unsigned)total), dim3(256), C::LDS_BYTES, ctx->cur_stream(), p);
+        MVLM_CHECK_HIP(ctx, hipGetLastError());
+        return 0;
+    }
 }
 
 

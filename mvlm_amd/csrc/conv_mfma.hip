@@ -37,10 +37,15 @@
 #include "conv_kernel.h"   // Cfg<> (tile geometry) for the compile-time queries below; kernels are not instantiated here
 #include "conv_variants.h"
 #include "conv_tuned.h"
+#include "conv_pair_tuned.h"
+#include <map>
+#include <mutex>
 #include <algorithm>
 
 // one launcher per variant, defined in conv_inst_g*.hip
-#define X(id, name, ...) int mvlm_conv_launch_##id(mvlm_ctx* ctx, const ConvArgs& a);
+#define X(id, name, ...)                                         \
+    int mvlm_conv_launch_##id(mvlm_ctx* ctx, const ConvArgs& a); \
+    int mvlm_conv_pair_launch_##id(mvlm_ctx* ctx, const ConvArgs& a0, const ConvArgs& a1);
 MVLM_CONV_VARIANTS(X)
 #undef X
 
@@ -121,15 +126,24 @@ int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt) {
 
 const char* mvlm_conv_variant_name_impl(int v) {
     if (v == MVLM_CONV_VARIANT_FAST) return "conv3x3_bf16x3_t8x32";
-    if (v >= 256 && v < 1024) {
-        // built once (thread-safe static initialisation): "<split-K variant>_k<parts>"
-        static const std::vector<std::string> names = [] {
-            std::vector<std::string> t(1024);
-            for (int id = 256; id < 1024; ++id)
-                t[size_t(id)] = std::string(mvlm_conv_variant_name_impl(id & 255)) + "_k" + std::to_string(1 << (id >> 8));
-            return t;
-        }();
-        return names[size_t(v)].c_str();
+    if (v >= 256) {
+        // "<split-K variant>_k<parts>" and "<variant>_pair[_k<parts0>k<parts1>]": built on first use, kept for the process
+        static std::mutex mu;
+        static std::map<int, std::string> names;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = names.find(v);
+        if (it == names.end()) {
+            std::string n = mvlm_conv_variant_name_impl(v & 255);
+            if (v & MVLM_CONV_PAIR_FLAG) {
+                n += "_pair";
+                const int l0 = (v >> 8) & 3, l1 = (v >> 10) & 3;
+                if (l0 || l1) n += "_k" + std::to_string(1 << l0) + "k" + std::to_string(1 << l1);
+            } else {
+                n += "_k" + std::to_string(1 << ((v >> 8) & 3));
+            }
+            it = names.emplace(v, n).first;
+        }
+        return it->second.c_str();
     }
     switch (v) {
 #define X(id, name, ...) \
@@ -153,6 +167,100 @@ bool mvlm_conv_can_pool(const ConvArgs& a) {
 #undef X
     }
     return false;
+}
+
+bool mvlm_conv_variant_can_pool(int v) {
+    switch (v & 255) {
+#define X(id, name, ...)                                                                                   \
+    case id: {                                                                                             \
+        using V = __VA_ARGS__;                                                                             \
+        return !V::SPLITK && !V::TAIL16 && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0;                  \
+    }
+        MVLM_CONV_VARIANTS(X)
+#undef X
+    }
+    return false;
+}
+
+namespace {
+// can variant `v` (base id) serve this problem, and does it exist as a two-problem kernel?
+bool pair_variant_serves(int v, const ConvArgs& a) {
+    switch (v) {
+#define X(id, name, ...)                                                                                                \
+    case id: {                                                                                                          \
+        using V = __VA_ARGS__;                                                                                          \
+        return V::PAIRABLE && a.ksize == V::KS && a.W % V::TW == 0 && a.H % V::TRI == 0 && a.cout_pad % V::COUT_T == 0 && \
+               a.cin_pad % V::CK == 0 && (!V::SPLITK || a.cin_pad % 32 == 0);                                           \
+    }
+        MVLM_CONV_VARIANTS(X)
+#undef X
+    }
+    return false;
+}
+}  // namespace
+
+// Should these two independent convolutions share a launch, and on which tiles?  Returns the pair's variant code
+// (MVLM_CONV_PAIR_FLAG | base id | log2(kparts of problem 0) << 8 | log2(kparts of problem 1) << 10) or -1 (two launches).
+//   mode 1: the measured table (conv_pair_tuned.h, tools/tune_conv_pairs.py: pairs that beat the two tuned single launches)
+//   mode 2: always, on the tiles the dispatcher would give problem 0 when they can serve both (tests, tuning)
+int mvlm_conv_pair_variant(const ConvArgs& a0, const ConvArgs& a1, int mode) {
+    if (mode <= 0) return -1;
+    for (const ConvArgs* a : {&a0, &a1})
+        if (a->ksize != 3 || a->amax_val || a->up_in || a->up_out == 2 || a->n_par != 1 || a->H != a->W) return -1;
+    if (a0.B != a1.B) return -1;
+    int v = -1;
+    if (mode == 2) {
+        for (int cand : {pick_variant(a0), pick_variant(a1), pick_variant_rules(a0), pick_variant_rules(a1)}) {
+            if (cand < 0) continue;
+            const int base = cand & 255, lg = cand >> 8;
+            if (pair_variant_serves(base, a0) && pair_variant_serves(base, a1)) {
+                v = base | (lg << 8) | (lg << 10);
+                break;
+            }
+        }
+        return v < 0 ? -1 : (v | MVLM_CONV_PAIR_FLAG);
+    }
+    if (MVLM_CONV_PAIR_TUNED_N == 0 || a0.cin_pad != a1.cin_pad || a0.cout_pad != a1.cout_pad || a0.H != 2 * a1.H) return -1;
+    const ConvPairTuned key = {short(a0.cin_pad), short(a0.cout_pad), short(a0.H), short(a0.B > 32767 ? 32767 : a0.B), 0};
+    auto less = [](const ConvPairTuned& x, const ConvPairTuned& y) {
+        if (x.cin_pad != y.cin_pad) return x.cin_pad < y.cin_pad;
+        if (x.cout_pad != y.cout_pad) return x.cout_pad < y.cout_pad;
+        if (x.size != y.size) return x.size < y.size;
+        return x.batch < y.batch;
+    };
+    const ConvPairTuned* end = MVLM_CONV_PAIR_TUNED + MVLM_CONV_PAIR_TUNED_N;
+    const ConvPairTuned* it = std::lower_bound(MVLM_CONV_PAIR_TUNED, end, key, less);  // smallest tuned batch >= B of this pair shape
+    if (it == end || it->cin_pad != key.cin_pad || it->cout_pad != key.cout_pad || it->size != key.size || it->variant < 0) return -1;
+    v = it->variant;
+    if (!pair_variant_serves(v & 255, a0) || !pair_variant_serves(v & 255, a1)) return -1;
+    return v | MVLM_CONV_PAIR_FLAG;
+}
+
+int mvlm_launch_conv_pair(mvlm_ctx* ctx, const ConvArgs& a0, const ConvArgs& a1, int pair_variant) {
+    MVLM_REQUIRE(ctx, pair_variant >= 0 && (pair_variant & MVLM_CONV_PAIR_FLAG) && pair_variant < 2 * MVLM_CONV_PAIR_FLAG, "conv: not a pair variant");
+    ConvArgs b[2] = {a0, a1};
+    for (int i = 0; i < 2; ++i) {
+        const ConvArgs& a = b[i];
+        MVLM_REQUIRE(ctx, a.in && a.w && a.B > 0 && a.H > 0 && a.W > 0 && a.H == a.W, "conv: null input / weights or bad shape");
+        MVLM_REQUIRE(ctx, !a.up_in && a.up_out != 2 && (a.up_out != 1 || a.skip), "conv: a paired launch takes plain or scattering 3x3 convolutions");
+        const double px = double(a.B) * a.H * a.W, lim = 4294967295.0;
+        MVLM_REQUIRE(ctx, px * a.in_ctot < lim && (!a.out_raw || px * a.raw_ctot < lim) && (!a.res1 || px * a.res1_ctot < lim) &&
+                              (!a.res2 || px * a.res2_ctot < lim) && (!a.out || px * a.out_ctot * (a.up_out ? 4 : 1) < lim) &&
+                              (a.up_out != 1 || px * a.skip_ctot * 4 < lim) && (!a.pool_out || px / 4 * a.pool_ctot < lim),
+                     "conv: a tensor exceeds 32-bit element offsets (lower the batch)");
+        MVLM_REQUIRE(ctx, a.out || a.pool_out, "conv: no output requested");
+        MVLM_REQUIRE(ctx, !a.pool_out || (mvlm_conv_variant_can_pool(pair_variant) && !(a.H & 1) && !a.up_out), "conv: this pair's kernel variant cannot emit the pooled tensor");
+    }
+    b[0].kparts = 1 << ((pair_variant >> 8) & 3);
+    b[1].kparts = 1 << ((pair_variant >> 10) & 3);
+    switch (pair_variant & 255) {
+#define X(id, name, ...) \
+    case id:             \
+        return mvlm_conv_pair_launch_##id(ctx, b[0], b[1]);
+        MVLM_CONV_VARIANTS(X)
+#undef X
+    }
+    return ctx->fail("conv: unreachable variant");
 }
 
 int mvlm_conv_amax_parts(int H, int W) {

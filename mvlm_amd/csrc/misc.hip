@@ -48,7 +48,7 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, long n_out, int Wo
 // reduce the conv epilogue's per-tile argmax partials to (row-1, col-0.5, value)
 // (paulsenpredictor.py:123-127): first maximum in row-major order.
 __global__ void amax_final_kernel(const float* __restrict__ val, const int* __restrict__ idx, int nl, int parts,
-                                  int size, int view0, int n_views_total, float* __restrict__ maxima) {
+                                  int size, int view0, int n_views_total, float* __restrict__ maxima, int* __restrict__ best_idx) {
     const int b = blockIdx.x / nl, lm = blockIdx.x % nl;
     const float* v = val + size_t(blockIdx.x) * parts;
     const int* ix = idx + size_t(blockIdx.x) * parts;
@@ -87,6 +87,7 @@ __global__ void amax_final_kernel(const float* __restrict__ val, const int* __re
         o[0] = float(bi / size) - 1.f;
         o[1] = float(bi % size) - 0.5f;
         o[2] = bv;
+        if (best_idx) best_idx[blockIdx.x] = bi;  // flat pixel index of the maximum (the moment refinement's window centre)
     }
 }
 
@@ -167,6 +168,105 @@ __global__ void heatmap_maxima_kernel(const float* __restrict__ heat, int n_view
     }
 }
 
+
+// "moment" selection without the [N,NL,256,256] heatmaps (paulsenpredictor.py:129-156).  The fused argmax has found the
+// peak of every (view, landmark) plane; where the reference refines it (peak more than 15 pixels from every border) this
+// kernel RECOMPUTES the 31x31 heatmap window around it from conv10's low-resolution output - the four parity forms of
+// conv11 (2x2 kernels over the 128x128 tensor, weights.collapse_upsampled_3x3) - and takes the centroid in numpy's order.
+// The window values are bit for bit those of the convolution kernel (conv2x2_c*_t8x32), whose f32 MFMAs are a k-ordered
+// fmaf chain (cdna_hip_programming.md, "FP32-input MFMA"): per output, chunks of 4 input channels, inside a chunk the four
+// taps in row-major order, inside a tap the chunk's channels - the 32-row tiles, the 16-row and the 4-row strip alike -
+// then + bias.  One workgroup per (view, landmark); a thread owns up to four window pixels; a chunk's 4 x 18 x 18 patch of
+// the low-resolution tensor is staged in LDS.  Planes whose peak is near a border keep the simple form amax_final wrote.
+struct MomentParityWeights {
+    const float* w[4];  // [tap][cin_pad][cout_pad] of parity 2 * (row & 1) + (col & 1)
+};
+
+__global__ __launch_bounds__(256) void moment_refine_kernel(const float* __restrict__ x10, int nl, int cin_pad, int cout_pad,
+                                                            const MomentParityWeights wp, const float* __restrict__ bias,
+                                                            const int* __restrict__ best_idx, int view0, int n_views_total,
+                                                            float* __restrict__ maxima) {
+    constexpr int SIZE = 256, LOW = 128, SZ = 15, WIN = 31, PATCH = 18;
+    const int b = blockIdx.x / nl, lm = blockIdx.x % nl;
+    const int bi = best_idx[blockIdx.x];
+    const int px = bi / SIZE, py = bi % SIZE;
+    if (!(px > SZ && SIZE - px > SZ && py > SZ && SIZE - py > SZ)) return;  // (uniform per workgroup)
+    extern __shared__ float smem_m[];
+    float* const sw = smem_m;                               // [parity][tap][cin_pad]: this landmark's weights
+    float* const sx = sw + 16 * cin_pad;                    // [4][PATCH][PATCH]
+    float* const win = sx + 4 * PATCH * PATCH;              // [WIN][WIN]
+    float* const rows = win + WIN * WIN;                    // [WIN], then cols [WIN]
+    float* const cols = rows + WIN;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 16 * cin_pad; e += 256) {
+        const int par = e / (4 * cin_pad), r = e - par * 4 * cin_pad;  // r = tap * cin_pad + channel
+        sw[e] = wp.w[par][size_t(r) * cout_pad + lm];
+    }
+    const int Y0 = px - SZ, X0 = py - SZ;
+    const int ly0 = (Y0 >> 1) - 1, lx0 = (X0 >> 1) - 1;     // low-resolution origin of the staged patch
+    int off[4], wbase[4];
+    bool ok[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = tid + 256 * j;
+        ok[j] = o < WIN * WIN;
+        const int wy = ok[j] ? o / WIN : 0, wx = ok[j] ? o % WIN : 0;
+        const int Y = Y0 + wy, X = X0 + wx;
+        const int a = Y & 1, c = X & 1;
+        off[j] = ((Y >> 1) + a - 1 - ly0) * PATCH + ((X >> 1) + c - 1 - lx0);  // top-left of the pixel's 2x2 window in the patch
+        wbase[j] = (2 * a + c) * 4 * cin_pad;
+    }
+    const float* const xb = x10 + size_t(b) * nl * LOW * LOW;
+    for (int cb = 0; cb < cin_pad; cb += 4) {
+        __syncthreads();  // the previous chunk's patch has been read
+        for (int e = tid; e < 4 * PATCH * PATCH; e += 256) {
+            const int ch = e / (PATCH * PATCH), r = e - ch * PATCH * PATCH;
+            const int gy = ly0 + r / PATCH, gx = lx0 + r % PATCH;
+            const bool in = cb + ch < nl && gy >= 0 && gy < LOW && gx >= 0 && gx < LOW;
+            sx[e] = in ? xb[(size_t(cb + ch) * LOW + gy) * LOW + gx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!ok[j]) continue;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+                    acc[j] = fmaf(sw[wbase[j] + tap * cin_pad + cb + ch], sx[ch * PATCH * PATCH + off[j] + (tap >> 1) * PATCH + (tap & 1)], acc[j]);
+        }
+    }
+    const float bv = bias ? bias[lm] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ok[j]) win[tid + 256 * j] = acc[j] + bv;
+    __syncthreads();
+    // the centroid, as in heatmap_maxima_kernel: np.sum(axis=1) = numpy's pairwise routine over the contiguous axis,
+    // np.sum(axis=0) adds row after row, the weighted sums run in float64 (np.arange is int64)
+    if (tid < WIN) {
+        const float* rowp = win + tid * WIN;
+        rows[tid] = np_sum31<float>([&](int j) { return rowp[j]; });
+    } else if (tid >= 64 && tid < 64 + WIN) {
+        const int t = tid - 64;
+        float s = 0.f;
+        for (int j = 0; j < WIN; ++j) s += win[j * WIN + t];
+        cols[t] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = np_sum31<double>([&](int j) { return double(j) * double(rows[j]); });
+        float ss = np_sum31<float>([&](int j) { return rows[j]; });
+        const double posx = s / double(ss) - SZ;
+        s = np_sum31<double>([&](int j) { return double(j) * double(cols[j]); });
+        ss = np_sum31<float>([&](int j) { return cols[j]; });
+        const double posy = s / double(ss) - SZ;
+        float* o = maxima + (size_t(lm) * n_views_total + view0 + b) * 3;
+        o[0] = float((double(px) + posx) - 1.0);
+        o[1] = float((double(py) + posy) - 0.5);
+    }
+}
+
 }  // namespace
 
 int mvlm_launch_pack_input(mvlm_ctx* ctx, const float* images, int n, const int* sel4, int c, float* out) {
@@ -190,9 +290,23 @@ int mvlm_launch_maxpool2(mvlm_ctx* ctx, const float* in, int planes, int H, int 
 }
 
 int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int n_img, int view0, int n_views_total,
-                           int nl, int parts, int size, float* maxima) {
+                           int nl, int parts, int size, float* maxima, int* best_idx) {
     hipLaunchKernelGGL(amax_final_kernel, dim3(n_img * nl), dim3(256), 0, ctx->cur_stream(), val, idx, nl, parts, size, view0,
-                       n_views_total, maxima);
+                       n_views_total, maxima, best_idx);
+    MVLM_CHECK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int mvlm_launch_moment_refine(mvlm_ctx* ctx, const float* x10, int n_img, int nl, int cin_pad, int cout_pad, const float* const w_par[4],
+                              const float* bias, const int* best_idx, int view0, int n_views_total, float* maxima) {
+    MVLM_REQUIRE(ctx, x10 && best_idx && maxima && w_par[0] && w_par[1] && w_par[2] && w_par[3], "moment: null argument");
+    MVLM_REQUIRE(ctx, cin_pad % 4 == 0 && cin_pad >= nl && cout_pad >= nl, "moment: bad channel padding");
+    MomentParityWeights wp;
+    for (int q = 0; q < 4; ++q) wp.w[q] = w_par[q];
+    const size_t lds = size_t(16 * cin_pad + 4 * 18 * 18 + 31 * 31 + 2 * 31) * sizeof(float);
+    MVLM_REQUIRE(ctx, lds <= 64 * 1024, "moment: too many input channels for the weight table in LDS");
+    hipLaunchKernelGGL(moment_refine_kernel, dim3(n_img * nl), dim3(256), lds, ctx->cur_stream(), x10, nl, cin_pad, cout_pad, wp, bias,
+                       best_idx, view0, n_views_total, maxima);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
 }

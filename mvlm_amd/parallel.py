@@ -14,6 +14,68 @@ import os
 import numpy as np
 
 
+# Optional timing of the two collectives of a sharded step (bench.py's scaling breakdown): enable_timing(True) makes
+# all_gather_views / broadcast_int32 bracket their collective - HIP events on the rank's current stream under RCCL (torch
+# orders the collective's stream against it on both sides), wall clock around a drained GPU under gloo - and
+# timing_summary() reports milliseconds per call.  Off by default: the product path records nothing.
+_TIMING = {"on": False, "all_gather": [], "broadcast": []}
+
+
+def enable_timing(on: bool) -> None:
+    _TIMING["on"] = bool(on)
+    _TIMING["all_gather"].clear()
+    _TIMING["broadcast"].clear()
+
+
+class _Timed:
+    def __init__(self, kind: str, on_device: bool):
+        self.kind, self.on_device, self.active = kind, on_device, _TIMING["on"]
+
+    def __enter__(self):
+        if not self.active:
+            return self
+        import time
+
+        import torch
+
+        if self.on_device:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()  # the host-staged form would otherwise count the GPU work it waits for
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.active or exc[0] is not None:
+            return False
+        import time
+
+        if self.on_device:
+            self.e1.record()
+            _TIMING[self.kind].append((self.e0, self.e1))
+        else:
+            _TIMING[self.kind].append(1e3 * (time.perf_counter() - self.t0))
+        return False
+
+
+def timing_summary() -> dict:
+    """Mean milliseconds per call of the collectives recorded since enable_timing(True) (synchronises the device)."""
+    out = {}
+    for kind in ("all_gather", "broadcast"):
+        vals = []
+        for rec in _TIMING[kind]:
+            if isinstance(rec, tuple):
+                rec[1].synchronize()
+                vals.append(rec[0].elapsed_time(rec[1]))
+            else:
+                vals.append(rec)
+        out[kind] = {"calls": len(vals), "mean_ms": (sum(vals) / len(vals)) if vals else None,
+                     "clock": "hip events on the rank's stream" if any(isinstance(r, tuple) for r in _TIMING[kind]) else "host wall clock"}
+    return out
+
+
 def is_distributed() -> bool:
     """A process group with more than one rank exists.  MVLM_DIST_WORLD_OF_ONE=1 also counts a group of ONE rank: the
     rehearsal of the sharded path (same collectives, tensors and devices) over RCCL on a one-GPU box."""
@@ -91,7 +153,8 @@ def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0, 
     t = torch.zeros(shape, dtype=torch.int32, device=_collective_device(device))
     if dist.get_rank() == src:
         t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)))
-    dist.broadcast(t, src=src)
+    with _Timed("broadcast", t.is_cuda):
+        dist.broadcast(t, src=src)
     if keep_on_device and t.is_cuda:
         return t
     return t.cpu().numpy()
@@ -113,11 +176,13 @@ def all_gather_views(local, n_total: int):
     recv = torch.empty((world * n_max, nl, 3), dtype=local.dtype, device=local.device)
     if dist.get_backend() == "gloo" and send.is_cuda:
         # rehearsal on one GPU (several ranks share a device, which RCCL refuses): stage through the host
-        r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_gather_into_tensor(r_cpu, send.cpu().contiguous())
-        recv.copy_(r_cpu)
+        with _Timed("all_gather", False):
+            r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(r_cpu, send.cpu().contiguous())
+            recv.copy_(r_cpu)
     else:
-        dist.all_gather_into_tensor(recv, send.contiguous())
+        with _Timed("all_gather", send.is_cuda):
+            dist.all_gather_into_tensor(recv, send.contiguous())
     parts = []
     for r in range(world):
         s, e = shard_range(n_total, r, world)

@@ -6,8 +6,8 @@ constructor arguments and ``predict_landmarks_from_images`` /
 ``get_lm_count`` contract.  The stacked-hourglass forward (:404-432), the
 batching loop (:189-212) and the heatmap maxima (:112-165) run as HIP kernels
 behind ``mvlm_cnn_maxima`` (mvlm_amd/csrc/cnn_graph.hip, conv_mfma.hip); the
-[N,NL,256,256] heatmaps are never materialised for the default "simple"
-selection method.
+[N,NL,256,256] heatmaps are never materialised, for the default "simple"
+selection method and for "moment" alike.
 """
 from __future__ import annotations
 
@@ -192,12 +192,21 @@ class HipPaulsenModel(Predictor2D):
         batch = self._batch_for(n)
         ws = self._get_workspace(batch, holder)
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        if self.selection_method == "simple":
+        # "moment" (:129-156) runs fused too: the 31x31 window around each peak is recomputed from conv10's output with
+        # conv11's own arithmetic (mvlm_cnn_set_selection) - no [N,NL,256,256] tensor.  MVLM_MOMENT_MATERIALISED=1 (tests) or
+        # packed weights without conv11's parity form take the heatmaps through HBM instead; the results are the same.
+        moment = self.selection_method == "moment"
+        fused = moment and os.environ.get("MVLM_MOMENT_MATERIALISED") != "1"
+        if fused and ctx.lib.mvlm_cnn_set_selection(ctx.handle, 1) != 0:
+            fused = False  # conv11 without its parity slots
+        if not fused:
+            ctx.check(ctx.lib.mvlm_cnn_set_selection(ctx.handle, 0))
+        if fused or not moment:
             ctx.check(ctx.lib.mvlm_cnn_maxima(
                 ctx.handle, C.c_void_p(x.data_ptr()), n, _lib.as_ptr(self.chan_sel, C.c_int32),
                 C.c_void_p(maxima.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), batch))
             return
-        for s in range(0, n, batch):  # "moment" needs the heatmap neighbourhood of each peak (:129-156)
+        for s in range(0, n, batch):
             nb = min(batch, n - s)
             heat = torch.empty((nb, nl, 256, 256), dtype=torch.float32, device=dev)
             part = torch.empty((nl, nb, 3), dtype=torch.float32, device=dev)
@@ -270,11 +279,17 @@ class HipPaulsenModel(Predictor2D):
             buf = bufs[name] = torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", holder.ctx.device))
         return buf
 
-    def set_execution(self, graphs: bool = True, concurrency: bool = False):
+    def set_execution(self, graphs: bool = True, concurrency: bool = False, pairing: int | None = None):
         """How the forward pass is issued (mvlm_cnn_set_execution): replayed hipGraphs / launch by launch, and
-        whether small batches run the lower hourglass pyramid on a second stream.  Results do not depend on it."""
+        (experiment only, measured slower) whether small batches run the lower hourglass pyramid on a second stream.
+        ``pairing`` (mvlm_cnn_set_pairing; None = leave as it is): 0 one launch per convolution, 1 (the default) independent
+        residual blocks of a hourglass level share launches where the measured table says that is faster, 2 wherever one
+        kernel variant can serve both.  graphs / concurrency never change a result; pairing may change the kernel variant
+        a convolution runs on, i.e. the last bits of its fp32 sums."""
         for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
             ctx.check(ctx.lib.mvlm_cnn_set_execution(ctx.handle, int(bool(graphs)), int(bool(concurrency))))
+            if pairing is not None:
+                ctx.check(ctx.lib.mvlm_cnn_set_pairing(ctx.handle, int(pairing)))
 
     def execution_stats(self) -> dict:
         v = [C.c_int64() for _ in range(4)]

@@ -392,14 +392,24 @@ def _shard_worker(rank, world, port, obj, q, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from mvlm_amd import pipeline
 
-    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False, shard_views=True)
+    # one rank per GPU under RCCL; the gloo rehearsal keeps every rank on the test box's one GPU
+    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False, shard_views=True,
+                                    device=rank if backend == "nccl" else 0)
     np.random.seed(4 if rank == 0 else 99)  # only rank 0's RNG may matter
     out = pipe.predict_one_file(obj)
     q.put((rank, out))
     dist.destroy_process_group()
 
 
-def test_sharded_views_equal_single_process(tmp_path):
+@pytest.mark.parametrize("backend", [
+    "gloo",
+    pytest.param("nccl", marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs one GPU per rank")),
+])
+def test_sharded_views_equal_single_process(tmp_path, backend):
+    """Two ranks, 6 of the 12 views each, must return exactly what a single process returns: over gloo with both ranks on
+    the test box's one GPU, and - on any machine that shows two GPUs - over RCCL ("nccl") with one rank per device, which is
+    the form bench.py --gpus N and the driver's 8-GPU run use (the reference's own multi-GPU mechanism is nn.DataParallel,
+    paulsenpredictor.py:100-105)."""
     import socket
 
     import torch.multiprocessing as mp
@@ -417,7 +427,7 @@ def test_sharded_views_equal_single_process(tmp_path):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, obj, q)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, obj, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)

@@ -59,13 +59,13 @@ def test_pre_align_block_through_predict_one_file(tmp_path, stem, n_views):
     np.random.seed(4)
     poses = pipe.renderer_3d.generate_3d_transformations()
     # a depth model's pipeline does not decode the JPEG (nothing reads the colour planes): the oracle renders untextured too
-    texture = raw.texture if pipe.renderer_3d.needs_texture else None
-    assert pipe.renderer_3d.needs_texture == (mode != "depth")
+    texture = raw.texture if pipe._texture_needed() else None
+    assert pipe._texture_needed() == (mode != "depth")
     with contextlib.redirect_stdout(io.StringIO()):
         want, _, inter = opipe.predict_mesh(verts, raw.tris, raw.uvs, texture, poses,
                                             weights.synthetic_state_dict(nl, c, seed=9), arch.CHANNEL_SELECT[mode])
     want = opre.landmarks_to_original_space(want, t)
-    mesh = pipe.renderer_3d.load_mesh(path)
+    mesh = pipe.renderer_3d.load_mesh(path, load_texture=pipe._texture_needed())
     assert mesh.to_original is not None
     images = pipe.renderer_3d.render_device(mesh, poses)
     np.testing.assert_array_equal(images.cpu().numpy(), inter["images"])
@@ -108,28 +108,48 @@ def test_predict_files_applies_pre_align_once(tmp_path):
         assert np.abs(a).max() < 12.0                      # file coordinates: a scan of +-5 units around (3, -2, 1.5)
 
 
-def test_depth_models_skip_the_texture_decode(tmp_path):
-    """A depth (or geometry) model never reads the colour planes: load_mesh leaves the JPEG alone (17 of 20 ms of a
-    2048x2048-texture scan's ingest) and the landmarks are those of the run that decoded it.  Writing the views out
-    (render_image_stack) or an RGB model brings the texture back."""
+def test_depth_models_skip_the_texture_decode(tmp_path, monkeypatch):
+    """A depth (or geometry) model never reads the colour planes: its pipeline asks load_mesh to leave the JPEG alone (17 of
+    20 ms of a 2048x2048-texture scan's ingest) and the landmarks are those of the run that decoded it.  Writing the views
+    out (render_image_stack) or an RGB model brings the texture back.  The choice is an argument of each load (round 4), not
+    renderer state: the renderer's own entry points always load the texture, whatever pipeline used the renderer before."""
     from mvlm_amd import pipeline
+    from mvlm_amd.utils import render3d
     from mvlm_amd.utils.synthetic import write_face_like_obj
 
     obj = write_face_like_obj(tmp_path / "face.obj", grid=40, tex_size=64, seed=1)
+    asked = []
+    real_load = render3d.load_obj
+
+    def spy(path, load_texture=True, **kw):
+        asked.append(bool(load_texture))
+        return real_load(path, load_texture=load_texture, **kw)
+
+    monkeypatch.setattr(render3d, "load_obj", spy)
     pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:3", image_mode="depth", verbose=False)
     np.random.seed(5)
     lean = pipe.predict_one_file(obj)
-    assert pipe.renderer_3d.needs_texture is False and pipe.renderer_3d.load_mesh(obj).texture is None
+    assert pipe._texture_needed() is False and asked == [False]
+    # direct use of the same renderer afterwards: texture loaded (the reference's behaviour, utils3d.py:26-36)
+    assert pipe.renderer_3d.load_mesh(obj).texture is not None
+    stack, _, handle = pipe.renderer_3d.multiview_render(obj)
+    assert handle.texture is not None and len(np.unique(stack[..., :3])) > 2
+    asked.clear()
     pipe.render_image_stack, pipe.render_image_folder = True, tmp_path
     np.random.seed(5)
     full = pipe.predict_one_file(obj)
-    assert pipe.renderer_3d.needs_texture is True and pipe.renderer_3d.load_mesh(obj).texture is not None
+    assert pipe._texture_needed() is True and asked == [True]
     np.testing.assert_array_equal(lean, full)
+    np.random.seed(5)
+    np.testing.assert_array_equal(pipe._predict_slots(obj), full)     # the slot protocol takes the same decision per call
     rgb = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:3", image_mode="RGB+depth", verbose=False)
-    assert rgb.predict_one_file(obj) is not None and rgb.renderer_3d.needs_texture is True
+    assert rgb.predict_one_file(obj) is not None and rgb._texture_needed() is True
     geo = pipeline.create_pipeline("dtu3d", n_views=8, weights="synthetic:3", image_mode="geometry+depth", verbose=False)
     geo.renderer_3d.shading = "geometry"
-    assert geo.predict_one_file(obj) is not None and geo.renderer_3d.needs_texture is False
+    asked.clear()
+    assert geo.predict_one_file(obj) is not None and geo._texture_needed() is False and asked == [False]
+    asked.clear()
+    assert [lm is not None for _, lm in geo.predict_files([obj, obj])] == [True, True] and asked == [False, False]
 
 
 @pytest.mark.parametrize("name,mode,n_views", [("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)])
@@ -282,8 +302,12 @@ def test_threads_with_planted_peaks_match_one_sequential_order():
         t.join()
     got = list(results.values())
     assert len(got) == 4
-    for s in seq:                                               # a permutation of the sequential results, bit for bit
-        assert sum(np.array_equal(s, g) for g in got) >= 1
+    # a permutation of the sequential results, bit for bit: every threaded result IS a sequential one, every sequential one
+    # occurs, and equal results occur equally often (the two multisets are the same)
+    from collections import Counter
+
+    key = lambda a: np.ascontiguousarray(a).tobytes()
+    assert Counter(key(g) for g in got) == Counter(key(s) for s in seq)
 
 
 def test_n_gpus_replicas_match_single_device(monkeypatch):
@@ -342,6 +366,11 @@ def test_bench_starts_its_own_ranks():
     assert "gloo world_size 2" in rec["config"]["parallelism"]
     assert rec["config"]["views_total"] == 16 and rec["config"]["views_per_gpu"] == "8"
     assert rec["value"] > 0 and rec["unit"] == "views/s" and rec["scaling"] == "strong"
+    # round 4: the line explains its own scaling - per-rank step times, the two collectives, the shard run unsharded
+    sb = rec["scaling_breakdown"]
+    assert len(sb["per_rank_ms_per_step"]["all"]) == 2 and sb["per_rank_ms_per_step"]["max"] == pytest.approx(rec["ms_per_step"], rel=1e-3)
+    assert sb["all_gather_ms_per_step"] > 0 and sb["draws_broadcast_ms_per_step"] > 0 and sb["collective_clock"] == "host wall clock"
+    assert sb["shard_views"] == 8 and 0 < sb["single_gpu_shard_ms"] < 2 * rec["ms_per_step"]
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -1,0 +1,383 @@
+"""Round-4 GPU tests: two independent convolutions in one grid (conv_pair_kernel) against the single launches and torch,
+the network with paired residual blocks, threads and ingest outside the pipeline lock, multi-device cases that run
+wherever two GPUs are visible.  Run with -m gpu."""
+import ctypes as C
+import threading
+import time
+from collections import Counter
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import seeded_images
+
+pytestmark = pytest.mark.gpu
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# (kernel variant code = base id | lg(kparts0) << 8 | lg(kparts1) << 10, name of the base, cin, cout, size of problem 0, batch)
+PAIR_CASES = [
+    (0, "conv3x3_c128_t8x32", 256, 128, 64, 2),            # the dominant tile: 64x64 beside 32x32
+    (10, "conv3x3_c64_t8x32", 128, 64, 128, 1),
+    (28, "conv3x3_c64k8_t8x16", 64, 64, 32, 3),
+    (27, "conv3x3_c32k8_t8x16", 128, 64, 32, 2),
+    (19, "conv3x3_sk16_t4x8", 256, 128, 16, 5),            # split-K tiles: 16x16 beside 8x8
+    (13, "conv3x3_sk_t4x8", 128, 64, 32, 1),
+    (19 | (1 << 10), "conv3x3_sk16_t4x8", 256, 128, 16, 3),  # ... the 8x8 problem's input channels over two workgroups
+    (20 | (1 << 8) | (2 << 10), "conv3x3_sk16_t4x4x2", 256, 128, 8, 5),  # 8x8 beside 4x4, K parts 2 and 4, odd image count
+    (24, "conv3x3_sk8_t4x4x2", 64, 64, 8, 12),
+]
+
+
+@pytest.mark.parametrize("code,name,cin,cout,size,batch", PAIR_CASES)
+def test_pair_launch_equals_single_launches(code, name, cin, cout, size, batch):
+    """conv j of a skip block and of the next level's first block in ONE grid: each problem's result (raw copy and
+    residual sum) equals, bit for bit, the single launch of the same kernel variant, and torch float64 within 5e-6."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    assert ctx.lib.mvlm_conv_variant_name(code & 255).decode() == name
+    assert ctx.lib.mvlm_conv_variant_name(code | 0x1000).decode().startswith(name + "_pair")
+    rs = np.random.RandomState(code + cin + size + batch)
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32))
+    xs, ws, rs_, ys, raws = [], [], [], [], []
+    for s in (size, size // 2):
+        xs.append(dev(rs.standard_normal((batch, cin, s, s)).astype(np.float32)))
+        ws.append((rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+        rs_.append(dev(rs.standard_normal((batch, cout, s, s)).astype(np.float32)))
+        ys.append(torch.full((batch, cout, s, s), np.nan, dtype=torch.float32, device="cuda"))
+        raws.append(torch.full((batch, cout, s, s), np.nan, dtype=torch.float32, device="cuda"))
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    ctx.check(ctx.lib.mvlm_conv2d_pair(ctx.handle, batch, cin, cout, ptr(xs[0]), size, p(ws[0]), ptr(rs_[0]), ptr(raws[0]), ptr(ys[0]),
+                                       ptr(xs[1]), size // 2, p(ws[1]), ptr(rs_[1]), ptr(raws[1]), ptr(ys[1]), p(pre[0]), p(pre[1]), code))
+    for i, s in enumerate((size, size // 2)):
+        single = torch.empty_like(ys[i])
+        lg = (code >> (8 + 2 * i)) & 3
+        ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, (code & 255) | (lg << 8)))
+        try:
+            ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, ptr(xs[i]), batch, cin, s, s, p(ws[i]), cout, 3, None, p(pre[0]), p(pre[1]),
+                                          None, None, ptr(rs_[i]), 0, ptr(single)))
+        finally:
+            ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, -1))
+        assert torch.equal(ys[i], single), f"problem {i}"
+        assert torch.equal(raws[i] + rs_[i], ys[i])              # raw copy = the value before the residual add
+        t = torch.relu(xs[i].cpu().double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
+                       + torch.from_numpy(pre[1]).double()[None, :, None, None])
+        want = (torch.nn.functional.conv2d(t, torch.from_numpy(ws[i]).double(), None, 1, 1) + rs_[i].cpu().double()).numpy()
+        assert np.abs(ys[i].cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+
+
+def test_pair_launch_refuses_what_it_cannot_serve():
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    x = torch.zeros((1, 64, 16, 16), device="cuda")
+    w = np.zeros((64, 64, 3, 3), np.float32)
+    y0, y1 = torch.empty((1, 64, 16, 16), device="cuda"), torch.empty((1, 64, 8, 8), device="cuda")
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+
+    def call(code, size1=8):
+        return ctx.lib.mvlm_conv2d_pair(ctx.handle, 1, 64, 64, ptr(x), 16, p(w), None, None, ptr(y0), ptr(x), size1, p(w), None, None,
+                                        ptr(y1), None, None, code)
+
+    assert call(16) != 0 and b"two-problem" in ctx.lib.mvlm_last_error(ctx.handle)      # the 80-row tile has no pair form
+    assert call(0) != 0 and b"multiple of the tile" in ctx.lib.mvlm_last_error(ctx.handle)  # 8x32-pixel tiles on 16x16
+    assert call(19 | (3 << 8)) != 0                                                          # 64 input channels do not divide into 8 parts of 16-channel chunks
+    assert call(19) == 0
+
+
+@pytest.mark.parametrize("n_views", [2, 12])
+def test_network_with_paired_residual_blocks(n_views):
+    """The forward pass with the hourglass's independent blocks sharing launches (pairing 2: wherever one kernel variant can
+    serve both; 1: the measured table) against the pass with one launch per convolution: the same network, so heatmaps agree
+    to fp32 rounding (another kernel variant = another summation order, like another device batch), the argmax pixel of every
+    plane is the same or a near-tie, and the launch graph is replayed in every mode."""
+    from mvlm_amd.prediction import DTU3DPredictor
+
+    imgs = dev(seeded_images(40 + n_views, n_views))
+    pred = DTU3DPredictor(image_mode="RGB", weights="synthetic:4", verbose=False)
+    out = torch.empty((73, n_views, 3), dtype=torch.float32, device="cuda")
+    pred.set_execution(graphs=False, pairing=0)
+    want = pred.predict_device(imgs, out=out).clone()
+    want_heat = pred.heatmaps_device(imgs[:2]).clone()
+    scale = float(want_heat.abs().max())
+    for mode in (2, 1):
+        pred.set_execution(graphs=False, pairing=mode)
+        eager = pred.predict_device(imgs, out=out).clone()
+        heat = pred.heatmaps_device(imgs[:2])
+        assert float((heat - want_heat).abs().max()) < 2e-5 * scale
+        same = torch.all(eager[:, :, :2] == want[:, :, :2], dim=2)
+        assert float(same.float().mean()) >= 0.99
+        assert float((eager[:, :, 2] - want[:, :, 2]).abs().max()) < 2e-5 * scale
+        pred.set_execution(graphs=True, pairing=mode)
+        before = pred.execution_stats()
+        for i in range(3):
+            out.zero_()
+            assert torch.equal(pred.predict_device(imgs, out=out), eager), f"mode {mode} pass {i}"
+        after = pred.execution_stats()
+        assert after["graph_failures"] == before["graph_failures"] and after["graph_replays"] >= before["graph_replays"] + 1
+    # the paired launches really ran in mode 2
+    ctx = pred.ctx
+    pred.set_execution(graphs=False, pairing=2)
+    ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 1))
+    try:
+        pred.predict_device(imgs, out=out)
+        cap = 512
+        slot, var = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+        fl, ms = (C.c_double * cap)(), (C.c_float * cap)()
+        n = ctx.lib.mvlm_cnn_get_profile(ctx.handle, slot, var, fl, ms, cap)
+    finally:
+        ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0))
+    pairs = [var[i] for i in range(n) if var[i] & 0x1000]
+    assert n == 138 - len(pairs) and len(pairs) >= 24, (n, len(pairs))
+    assert all(b"_pair" in ctx.lib.mvlm_conv_variant_name(v) for v in pairs)
+    pred.set_execution(graphs=True, pairing=1)
+
+
+# ---- cases that need two GPUs: collected everywhere, run wherever two devices are visible ---------------------------------
+two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+
+
+@two_gpus
+def test_n_gpus_replicas_on_two_devices():
+    """``n_gpus=2`` with the replica on a SECOND device (paulsenpredictor.py:100-105, nn.DataParallel): device-to-device
+    scatter of the views, the replica's pass on its own stream and launch graph, the peer write of its maxima slice - bit
+    for bit the single-device result, launch by launch and replayed.  (The one-GPU box only rehearses this with every replica
+    on device 0: tests/test_gpu_round3.py.)"""
+    from mvlm_amd.prediction import DTU3DPredictor
+
+    x = torch.from_numpy(seeded_images(3, 9)).cuda()
+    single = DTU3DPredictor(image_mode="RGB", weights="synthetic:5", verbose=False)
+    multi = DTU3DPredictor(image_mode="RGB", weights="synthetic:5", verbose=False, n_gpus=2)
+    assert [r.ctx.device for r in multi._replicas] == [1]
+    for n in (9, 4, 2):
+        # every device's share has its own batch size: compare with the single device run on the same shares
+        from mvlm_amd.parallel import shard_range
+
+        want = torch.cat([single.predict_device(x[slice(*shard_range(n, r, 2))].contiguous()) for r in range(2)], dim=1).cpu().numpy()
+        out = torch.empty((73, n, 3), device="cuda:0")
+        for _ in range(3):  # launch by launch, capture, replay - on both devices
+            got = multi.predict_device(x[:n].contiguous(), out=out).cpu().numpy()
+            np.testing.assert_array_equal(got, want)
+
+
+@two_gpus
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` exactly as the driver starts it, one RCCL rank per GPU: the JSON line carries the
+    scaling breakdown (per-rank times, the two collectives' times, the shard run unsharded)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MVLM_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-views", "0",
+                        "--no-fast-mode", "--views-total", "24"], capture_output=True, text=True, timeout=900, cwd=str(REPO),
+                       env=dict(env, MVLM_BENCH_NO_INGEST="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert rec["n_gpus"] == 2 and "nccl world_size 2" in rec["config"]["parallelism"]
+    sb = rec["scaling_breakdown"]
+    assert len(sb["per_rank_ms_per_step"]["all"]) == 2 and sb["single_gpu_shard_ms"] > 0
+    assert sb["all_gather_ms_per_step"] is not None and sb["collective_clock"].startswith("hip events")
+
+
+# ---- threads on one pipeline --------------------------------------------------------------------------------------------
+def test_threads_at_twelve_views_follow_the_admission_order(tmp_path):
+    """12 views: the poses come from the global RNG too (render3d.py:79-89), so a threaded run equals the sequential run IN
+    THE ORDER THE PIPELINE LOCK ADMITTED THE CALLS.  The order is recorded under the lock (ingest runs outside it since round
+    4, so it is not the order of the calls), then replayed sequentially from the same seed: bit for bit the same."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    files = [write_face_like_obj(tmp_path / f"s{i}.obj", grid=36 + 8 * i, tex_size=64, seed=i + 1) for i in range(3)]
+    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:3", verbose=False)
+    admitted = []
+    fused = pipe._predict_fused
+
+    def recording(file_name, mesh=None):
+        admitted.append(Path(file_name).name)   # called with the pipeline lock held
+        return fused(file_name, mesh=mesh)
+
+    pipe._predict_fused = recording
+    for attempt in range(3):
+        admitted.clear()
+        out, errors = {}, []
+        start = threading.Barrier(3)
+
+        def work(f):
+            try:
+                start.wait()
+                out[f.name] = pipe.predict_one_file(f)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        np.random.seed(70 + attempt)
+        threads = [threading.Thread(target=work, args=(f,)) for f in files]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        order = list(admitted)
+        assert sorted(order) == sorted(f.name for f in files)
+        np.random.seed(70 + attempt)
+        for name in order:
+            want = pipe.predict_one_file(tmp_path / name)
+            np.testing.assert_array_equal(out[name], want)
+
+
+def test_ingest_runs_outside_the_pipeline_lock(tmp_path):
+    """predict_one_file parses the OBJ and decodes the JPEG BEFORE it takes the pipeline lock (general_pipeline.py: load ->
+    lock -> GPU section): two server threads (3DMD_server.py:26-31) x two RGB scans with a 2048x2048 texture finish in less
+    than 1.6 x the time one thread needs for its two scans (2.0 x if the ingest were serialised with the GPU section), and
+    give the sequential results."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    files = [write_face_like_obj(tmp_path / f"rgb{i}.obj", grid=224, tex_size=2048, seed=i) for i in range(4)]
+    pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:3", verbose=False, image_mode="RGB+depth")
+    for f in files:
+        pipe.predict_one_file(f)          # page cache, launch graph, buffers
+    torch.cuda.synchronize()
+    want = {f.name: pipe.predict_one_file(f) for f in files}   # the fixed 8-view table: no RNG in the poses, draws only with >= 3 survivors
+
+    def one_thread():
+        t0 = time.perf_counter()
+        for f in files[:2]:
+            pipe.predict_one_file(f)
+        return time.perf_counter() - t0
+
+    def two_threads():
+        got = {}
+
+        def work(mine):
+            for f in mine:
+                got[f.name] = pipe.predict_one_file(f)
+
+        threads = [threading.Thread(target=work, args=(files[:2],)), threading.Thread(target=work, args=(files[2:],))]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return time.perf_counter() - t0, got
+
+    t1 = min(one_thread() for _ in range(3))
+    best, got = None, None
+    for _ in range(3):
+        t2, got = two_threads()
+        best = t2 if best is None else min(best, t2)
+    assert set(got) == set(want)
+    assert best < 1.6 * t1, f"two threads x two scans {1e3 * best:.1f} ms, one thread x two scans {1e3 * t1:.1f} ms"
+    assert pipe.timings["load"] > 0 and pipe.timings["total"] > pipe.timings["load"]
+
+
+# ---- "moment" selection out of the fused path (paulsenpredictor.py:129-156) ----------------------------------------------
+@pytest.mark.parametrize("cls_name,mode,n_views,device_batch", [("dtu3d", "RGB", 5, 2), ("bu3dfe", "RGB+depth", 3, None), ("dtu3d", "geometry+depth", 2, None)])
+def test_fused_moment_equals_the_materialised_heatmaps(monkeypatch, cls_name, mode, n_views, device_batch):
+    """selection_method="moment" without the [N,NL,256,256] tensor: the 31x31 window around each fused-argmax peak is
+    recomputed from conv10's output with conv11's own arithmetic (80-row tiles with the 16-row strip for 73 landmarks, 84
+    rows with the 4-row strip for 84).  Bit for bit (a) the same network's heatmaps through HBM + mvlm_heatmap_maxima and
+    (b) the oracle's moment rule (the reference's find_heat_map_maxima restated) on those heatmaps; device batches smaller
+    than the view count (view offsets) included; the launch graph is replayed."""
+    from mvlm_amd.prediction import BU3DFEPredictor, DTU3DPredictor
+    from oracle import cnn as ocnn
+
+    cls = DTU3DPredictor if cls_name == "dtu3d" else BU3DFEPredictor
+    imgs = dev(seeded_images(60 + n_views, n_views))
+    pred = cls(image_mode=mode, weights="synthetic:9", selection_method="moment", verbose=False, device_batch=device_batch)
+    nl = pred.get_lm_count()
+    out = torch.empty((nl, n_views, 3), dtype=torch.float32, device="cuda")
+    before = pred.execution_stats()
+    fused = [pred.predict_device(imgs, out=out).clone() for _ in range(3)]   # launch by launch, capture, replay
+    after = pred.execution_stats()
+    assert after["graph_replays"] > before["graph_replays"] and after["graph_failures"] == before["graph_failures"]
+    assert torch.equal(fused[0], fused[1]) and torch.equal(fused[0], fused[2])
+    monkeypatch.setenv("MVLM_MOMENT_MATERIALISED", "1")
+    materialised = pred.predict_device(imgs).cpu().numpy()
+    monkeypatch.delenv("MVLM_MOMENT_MATERIALISED")
+    got = fused[0].cpu().numpy()
+    np.testing.assert_array_equal(got, materialised)
+    heat = pred.heatmaps_device(imgs).cpu().numpy()
+    np.testing.assert_array_equal(got, ocnn.maxima_from_heatmaps(heat, "moment"))
+    pred.selection_method = "simple"                    # a plain attribute in the reference (paulsenpredictor.py:57): switchable
+    simple = pred.predict_device(imgs).cpu().numpy()
+    np.testing.assert_array_equal(simple, ocnn.maxima_from_heatmaps(heat, "simple"))
+    refined = np.any(got[:, :, :2] != simple[:, :, :2], axis=2)
+    assert refined.mean() > 0.5                         # most peaks lie > 15 px inside; the others keep the simple form
+    np.testing.assert_array_equal(got[:, :, 2], simple[:, :, 2])
+
+
+def test_fused_moment_on_planted_peaks_end_to_end():
+    """The planted detector (tests/planted.py: the final heatmaps peak at known surface points) with "moment" through
+    predict_mesh_device - render, network, fused argmax, window recomputation, centroid, rays, RANSAC inlier refit, snap -
+    equals the oracle's pipeline run with the same selection method, and finds the planted points."""
+    import contextlib
+    import io
+
+    from mvlm_amd import arch, config
+    from mvlm_amd.pipeline import pipeline_from_config
+    from oracle import estimator as oest
+    from oracle import cnn as ocnn
+    from test_planted_cpu import planted_scene
+
+    mesh, pts, sd, poses = planted_scene(n_views=16)
+    pipe = pipeline_from_config(config.default_config("DTU3D", "RGB", n_views=16), weights=sd, verbose=False)
+    pipe.predictor_2d.selection_method = "moment"
+    np.random.seed(1)
+    got, err = pipe.predict_mesh_device(mesh, poses)
+    assert err < 10.0
+    images = pipe.renderer_3d.render_device(mesh, poses)
+    gmax = pipe.predictor_2d.predict_device(images).cpu().numpy()
+    heat = pipe.predictor_2d.heatmaps_device(images).cpu().numpy()
+    np.testing.assert_array_equal(gmax, ocnn.maxima_from_heatmaps(heat, "moment"))
+    s, e = oest.estimate_landmark_lines(256, gmax, poses)
+    np.random.seed(1)
+    want, werr = oest.estimate_landmarks_from_lines(gmax, s, e)
+    from oracle import surface
+
+    np.testing.assert_allclose(got, surface.project_landmarks_to_surface(mesh.verts, mesh.tris, want), rtol=0, atol=1e-8)
+    d = np.linalg.norm(got - pts, axis=1)
+    assert d.max() < 6.0 and np.median(d) < 4.0
+
+
+def test_batched_scans_write_the_pre_aligned_mesh_too(tmp_path):
+    """pre-align.write_pre_aligned (utils3d.py:489-494) on the grouped path: predict_files(batch_scans=2) writes
+    <stem>_pre_transform_mesh.vtk for every scan, as the one-by-one loop does."""
+    from mvlm_amd import config
+    from mvlm_amd.pipeline import pipeline_from_config
+    from mvlm_amd.utils.mesh_io import write_obj
+    from mvlm_amd.utils.synthetic import face_like_mesh, unaligned_copy
+
+    cfg = config.default_config("DTU3D-RGB_Artec3D", n_views=8)
+    assert cfg["pre-align"]["write_pre_aligned"]
+    cfg["process_3d"]["write_renderings"] = False
+    files = []
+    for sd in (1, 2, 3):
+        raw = unaligned_copy(face_like_mesh(40, 64, sd), cfg["pre-align"])
+        path = tmp_path / f"scan{sd}.obj"
+        write_obj(path, raw.verts, raw.tris, raw.uvs, raw.texture)
+        files.append(path)
+    pipe = pipeline_from_config(cfg, weights="synthetic:9", verbose=False)
+    out_dir = tmp_path / "aligned"
+    out_dir.mkdir()
+    pipe.write_pre_aligned_folder = out_dir
+    assert pipe._groupable(2)
+    np.random.seed(2)
+    res = [lm for _, lm in pipe.predict_files(files, batch_scans=2)]
+    assert all(lm is not None for lm in res)
+    for f in files:
+        vtk = out_dir / f"{f.stem}_pre_transform_mesh.vtk"
+        assert vtk.exists() and "POLYDATA" in vtk.read_text()[:200]
