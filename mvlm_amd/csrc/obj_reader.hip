@@ -7,11 +7,14 @@
 // The corner numbering is the contract with mvlm_amd/utils/mesh_io.py:_parse_obj (the pure-Python
 // statement of the same rules, kept as the cross-check in tests): corners are numbered in order of
 // first use of each (v, vt) pair, negative indices are relative to the elements read so far.
+#include <sched.h>
+
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -241,12 +244,44 @@ void parse_chunk(Chunk* c) {
     c->lines = line_no;
 }
 
+// CPUs this process may really use: the scheduler affinity mask, capped by the cgroup's CPU quota (a container on a
+// 256-thread host is typically granted 8 or 16) - std::thread::hardware_concurrency() reports the host
+long usable_cpus() {
+    long n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = long(std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = strtol(quota, nullptr, 10) / period;
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
+
 int reader_threads(size_t bytes) {
     long want = long(bytes / (256u << 10));  // a thread per 256 KB of text, at most 8
     if (const char* e = getenv("MVLM_OBJ_THREADS")) want = strtol(e, nullptr, 10);
-    const long hw = long(std::thread::hardware_concurrency());
-    if (!getenv("MVLM_OBJ_THREADS") && hw > 0 && want > hw) want = hw;
+    static const long cpus = usable_cpus();
+    if (!getenv("MVLM_OBJ_THREADS") && want > cpus) want = cpus;
     return int(want < 1 ? 1 : want > 8 ? 8 : want);
+}
+
+// parse_chunk with the boundary's promise kept: nothing throws out of it (an allocation failure becomes the chunk's error)
+void parse_chunk_guarded(Chunk* c) noexcept {
+    try {
+        parse_chunk(c);
+    } catch (const std::exception&) {
+        if (c->err_line <= 0) c->err_line = c->lines + 1;
+        c->err_what = "out of memory while parsing";
+    } catch (...) {
+        if (c->err_line <= 0) c->err_line = c->lines + 1;
+        c->err_what = "internal error while parsing";
+    }
 }
 
 }  // namespace
@@ -280,9 +315,21 @@ extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int er
             while (next < eof && next > base && next[-1] != '\n' && next[-1] != '\r') ++next;
             chunks[size_t(k)].end = cut = next;
         }
+        // A worker that cannot be started (EAGAIN under a pids limit: predict_files runs several readers) must not unwind
+        // through joinable threads (std::terminate in a process that owns the GPU): its chunk and the remaining ones are
+        // parsed on this thread, the workers already running are joined as usual.
         std::vector<std::thread> workers;
-        for (int k = 1; k < n_chunks; ++k) workers.emplace_back(parse_chunk, &chunks[size_t(k)]);
-        parse_chunk(&chunks[0]);
+        workers.reserve(size_t(n_chunks));
+        int started = 1;  // chunks [1, started) have a worker
+        for (; started < n_chunks; ++started) {
+            try {
+                workers.emplace_back(parse_chunk_guarded, &chunks[size_t(started)]);
+            } catch (...) {
+                break;
+            }
+        }
+        parse_chunk_guarded(&chunks[0]);
+        for (int k = started; k < n_chunks; ++k) parse_chunk_guarded(&chunks[size_t(k)]);
         for (auto& w : workers) w.join();
     }
     // ---- the first error in file order is the one a sequential parse stops at

@@ -155,8 +155,9 @@ def test_depth_models_skip_the_texture_decode(tmp_path, monkeypatch):
 @pytest.mark.parametrize("name,mode,n_views", [("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)])
 def test_fast_precision_against_the_oracle(name, mode, n_views):
     """precision="fast" (opt-in bf16x3 arithmetic, never the default, never bench.py's value) against the CPU ORACLE, not
-    just against the exact path: the same render, < 1 % of the argmax planes move (near-ties), and every landmark whose
-    views all picked the oracle's pixel lands within 1e-3 model units.  Full-size figures: profiles/r03_fast_vs_oracle_*."""
+    just against the exact path: the same render, at most 0.1 % of the argmax planes move (near-ties; measured at full size:
+    1 of 8 064 and 0 of 4 672, profiles/r03_fast_vs_oracle_*), and every landmark whose views all picked the oracle's
+    pixel lands within 1e-3 model units."""
     from mvlm_amd import arch, pipeline, weights
     from mvlm_amd.utils.synthetic import face_like_mesh
     from oracle import pipeline as opipe
@@ -177,9 +178,9 @@ def test_fast_precision_against_the_oracle(name, mode, n_views):
                                             weights.synthetic_state_dict(nl, arch.IMAGE_CHANNELS[mode], seed=11),
                                             arch.CHANNEL_SELECT[mode])
     diff = ~np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)
-    assert diff.mean() <= 0.01
+    assert diff.mean() <= 0.001, f"{int(diff.sum())} of {diff.size} argmax planes differ from the oracle"
     same = ~diff.any(axis=1)
-    assert same.mean() > 0.8
+    assert same.mean() > 0.95
     assert np.abs(got[same] - want[same]).max() < 1e-3
     scores = np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[~diff]
     assert scores.max() < 1e-4 * max(1.0, np.abs(inter["maxima"][:, :, 2]).max())
