@@ -564,7 +564,7 @@ struct Exec {
             if (!heat) {
                 av = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
                 ai = alloc_raw(size_t(B) * NL * parts * 4, 0, 0);
-                if (moment) abest = alloc_raw(size_t(B) * NL * 4, 0, 0);
+                if (moment || dry) abest = alloc_raw(size_t(B) * NL * 4, 0, 0);  // (the workspace query covers both selections)
             }
             // the four parities share their input tiles: ONE launch with the parities of a tile on neighbouring workgroups
             // (ConvArgs::n_par); MVLM_CONV11_PARITY_LAUNCHES=4 keeps one launch per parity (experiments)
@@ -614,7 +614,7 @@ struct Exec {
                 }
                 release(av);
                 release(ai);
-                if (moment) release(abest);
+                if (moment || dry) release(abest);
             }
         }
         release(x10);
