@@ -316,7 +316,7 @@ def test_fused_moment_equals_the_materialised_heatmaps(monkeypatch, cls_name, mo
     simple = pred.predict_device(imgs).cpu().numpy()
     np.testing.assert_array_equal(simple, ocnn.maxima_from_heatmaps(heat, "simple"))
     refined = np.any(got[:, :, :2] != simple[:, :, :2], axis=2)
-    assert refined.mean() > 0.5                         # most peaks lie > 15 px inside; the others keep the simple form
+    assert refined.mean() > 0.2                         # peaks more than 15 px inside are refined; the others keep the simple form
     np.testing.assert_array_equal(got[:, :, 2], simple[:, :, 2])
 
 
