@@ -350,7 +350,9 @@ def test_fused_moment_on_planted_peaks_end_to_end():
 
     np.testing.assert_allclose(got, surface.project_landmarks_to_surface(mesh.verts, mesh.tris, want), rtol=0, atol=1e-8)
     d = np.linalg.norm(got - pts, axis=1)
-    assert d.max() < 6.0 and np.median(d) < 4.0
+    # (the planted heatmaps are hat functions on a sloped background: their 31x31 centroid sits a little further from the
+    #  knot than the argmax pixel does - 6.9 units at worst against 6.0 with "simple")
+    assert d.max() < 8.0 and np.median(d) < 4.0
 
 
 def test_batched_scans_write_the_pre_aligned_mesh_too(tmp_path):
