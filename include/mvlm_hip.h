@@ -162,6 +162,15 @@ int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int 
 int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled);
 int mvlm_cnn_get_profile(mvlm_ctx* ctx, int32_t* slot, int32_t* variant, double* flops, float* ms, int cap);
 const char* mvlm_conv_variant_name(int variant);
+/* shapes of those records, in the same order: {ksize, cin_pad, cout_pad, size, kind, batch} per record (kind: 0 plain /
+ * residual-block layer, 1 scatter into the skip tensor, 2 pooled output wanted; slot -1 = the pool kernel: channels in
+ * cout_pad).  Returns the record count. */
+int mvlm_cnn_get_profile_shapes(mvlm_ctx* ctx, int32_t* shapes6, int cap);
+/* tuning hooks of tools/tune_in_network.py: mvlm_conv_variant_serves - can kernel variant `variant` run a 3x3 layer of this
+ * shape and kind (1 / 0); mvlm_conv_set_override - every launch of this (shape, kind) on this context runs that variant,
+ * ahead of the measured tables (variant < 0 removes the entry, ksize 0 all of them). */
+int mvlm_conv_variant_serves(int variant, int ksize, int cin_pad, int cout_pad, int size, int kind);
+int mvlm_conv_set_override(mvlm_ctx* ctx, int ksize, int cin_pad, int cout_pad, int size, int kind, int variant);
 
 /* heatmap maxima of materialised heatmaps (replaces paulsenpredictor.py:112-165).
  * heat_dev f32[N,NL,S,S] -> out_dev f32[NL,N,3]. */

@@ -61,6 +61,9 @@ SIGNATURES = {
     "mvlm_cnn_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_cnn_get_profile": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_float_p, C.c_int]),
     "mvlm_conv_variant_name": (C.c_char_p, [C.c_int]),
+    "mvlm_cnn_get_profile_shapes": (C.c_int, [C.c_void_p, c_int32_p, C.c_int]),
+    "mvlm_conv_variant_serves": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mvlm_conv_set_override": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mvlm_heatmap_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mvlm_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int,
                               c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -210,7 +210,10 @@ struct Exec {
         }
         if (st.profiling) {
             hipEventRecord(e1, ctx->cur_stream());
-            st.prof.push_back({slot, variant, conv_flops(a), e0, e1});
+            ConvProfileRec rec{slot, variant, conv_flops(a), e0, e1};
+            const short sh[6] = {short(a.ksize), short(a.cin_pad), short(a.cout_pad), short(a.H), short(mvlm_conv_kind(a)), short(B > 32767 ? 32767 : B)};
+            for (int k = 0; k < 6; ++k) rec.shape[k] = sh[k];
+            st.prof.push_back(rec);
         }
         return 0;
     }
@@ -303,6 +306,8 @@ struct Exec {
         P.a[1].out_raw = P.t2.p;
         P.a[1].raw_ctot = q;
         P.want_pool = pooled && !hi;
+        if (P.want_pool)
+            for (ConvArgs& a : P.a) a.pool_hint = 1;  // the variant choice knows the pooled tensor is wanted, fused or not
         P.keep_full = keep_full;
         P.pooled = pooled;
         if (P.want_pool) *pooled = alloc(cout, P.S / 2);
@@ -323,7 +328,24 @@ struct Exec {
     void finish_rb(RbPlan& P) {
         release(P.t1);
         release(P.t2);
-        if (P.want_pool && !P.a[0].pool_out && !dry && !rc && mvlm_launch_maxpool2(ctx, P.y.p, B * P.cout, P.S, P.S, P.pooled->p)) rc = 1;
+        if (P.want_pool && !P.a[0].pool_out && !dry && !rc) pool_kernel(P.y.p, P.cout, P.S, P.pooled->p);
+    }
+    // F.max_pool2d as its own launch (the block's kernel variants cannot pool in their epilogues); profiled as slot -1
+    void pool_kernel(const float* in, int channels, int S, float* out) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof_begin(e0, e1)) return;
+        if (mvlm_launch_maxpool2(ctx, in, B * channels, S, S, out)) {
+            rc = 1;
+            return;
+        }
+        if (st.profiling) {
+            hipEventRecord(e1, ctx->cur_stream());
+            ConvProfileRec rec{-1, -1, 0.0, e0, e1};
+            rec.shape[2] = short(channels);
+            rec.shape[3] = short(S);
+            rec.shape[5] = short(B > 32767 ? 32767 : B);
+            st.prof.push_back(rec);
+        }
     }
 
     Tensor rb(int rb_index, const Tensor& x, Tensor* hi, Tensor* pooled = nullptr, bool keep_full = true) {
@@ -386,7 +408,7 @@ struct Exec {
         a.B = B;
         a.H = a.W = S;
         (void)x;
-        return mvlm_conv_can_pool(a);
+        return mvlm_conv_can_pool(ctx, a);
     }
 
     // HourGlassModule.forward (paulsenpredictor.py:301-361).  rb0 = index of this
@@ -520,13 +542,14 @@ struct Exec {
             a.out = sum.p;
             a.out_ctot = 256;
             sump = alloc(256, 64);
+            a.pool_hint = 1;
             const bool fused = pool_fusable(SLOT_CONV5 + 2, x6, a, 128);
             if (fused) {
                 a.pool_out = sump.p;
                 a.pool_ctot = 256;
             }
             conv(SLOT_CONV5 + 2, x6, a, 128);
-            if (!fused && !dry && !rc && mvlm_launch_maxpool2(ctx, sum.p, B * 256, 128, 128, sump.p)) rc = 1;
+            if (!fused && !dry && !rc) pool_kernel(sum.p, 256, 128, sump.p);
         }
         release(x6);
         release(r3);
@@ -950,6 +973,18 @@ extern "C" int mvlm_cnn_get_profile(mvlm_ctx* ctx, int32_t* slot, int32_t* varia
         variant[n] = r.variant;
         flops[n] = r.flops;
         ms[n] = t;
+        ++n;
+    }
+    return n;
+}
+
+// shapes of the records mvlm_cnn_get_profile returns, in the same order: {ksize, cin_pad, cout_pad, size, kind, batch} per record
+extern "C" int mvlm_cnn_get_profile_shapes(mvlm_ctx* ctx, int32_t* shapes6, int cap) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int n = 0;
+    for (const auto& r : ctx->cnn.prof) {
+        if (n >= cap) break;
+        for (int k = 0; k < 6; ++k) shapes6[n * 6 + k] = r.shape[k];
         ++n;
     }
     return n;

@@ -112,6 +112,7 @@ struct ConvArgs {
     // pool_out is [B][pool_ctot][H/2][W/2]; `out` may be null when only the pooled tensor is consumed
     float* pool_out = nullptr;
     int pool_ctot = 0, pool_coff = 0;
+    int pool_hint = 0;  // the caller wants the pooled tensor too (set for the variant choice, before pool_out is decided)
     // -DMVLM_CONV_TIMING builds only (tools/conv_phase_timing.py): u64[4] = summed cycles of wave 0 in
     // prologue / K loop / epilogue, number of workgroups
     unsigned long long* timing = nullptr;
@@ -121,6 +122,15 @@ struct ConvProfileRec {
     int slot, variant;
     double flops;
     hipEvent_t e0, e1;
+    short shape[6] = {0, 0, 0, 0, 0, 0};  // ksize, cin_pad, cout_pad, size, kind (conv_kind), batch; slot -1 = the pool kernel
+};
+
+// Dispatch key of a convolution launch beyond its shape: 0 plain / residual-block layer, 1 the value is scattered 2x2 into
+// the skip tensor (hourglass way up), 2 the 2x2 max-pooled tensor is wanted as well.  The measured tables and the tuning
+// overrides are kept per kind: the epilogues differ, and so does the best tile.
+struct ConvOverride {
+    short ksize, cin_pad, cout_pad, size, kind;
+    int variant;
 };
 
 // one captured forward pass (hipGraph) of the network for a fixed set of buffers and shapes
@@ -204,6 +214,7 @@ struct mvlm_ctx {
     float* kparts_ws[2] = {nullptr, nullptr};      // split-K over workgroups: partial tiles, arrival counters
     unsigned* kparts_cnt[2] = {nullptr, nullptr};  // ([0] main launch stream, [1] the executor's side stream)
     int conv_force_variant = -1;            // >= 0: mvlm_conv_bench times exactly this kernel variant
+    std::vector<ConvOverride> conv_overrides;  // tools/tune_in_network.py: kernel variant per (shape, kind), before any table
     unsigned long long conv_attr_mask = 0;  // conv variants whose launch attributes are set on this ctx's device
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render
@@ -268,7 +279,8 @@ constexpr long MVLM_KPARTS_MAX_TILES = 2048;  // output tiles of a launch that d
 constexpr long MVLM_KPARTS_MAX_PARTS = 4096;  // tiles x parts (4 KB of partial sums each)
 int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt);
 int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
-bool mvlm_conv_can_pool(const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
+bool mvlm_conv_can_pool(const mvlm_ctx* ctx, const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
+int mvlm_conv_kind(const ConvArgs& a);
 bool mvlm_conv_variant_can_pool(int variant);
 // two independent convolutions in one grid (conv_kernel.h: conv_pair_kernel)
 constexpr int MVLM_CONV_PAIR_FLAG = 0x1000;  // variant code of a paired launch: flag | base id | lg(kparts0) << 8 | lg(kparts1) << 10

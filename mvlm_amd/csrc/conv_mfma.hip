@@ -37,6 +37,7 @@
 #include "conv_kernel.h"   // Cfg<> (tile geometry) for the compile-time queries below; kernels are not instantiated here
 #include "conv_variants.h"
 #include "conv_tuned.h"
+#include "conv_tuned_net.h"
 #include "conv_pair_tuned.h"
 #include <map>
 #include <mutex>
@@ -85,13 +86,37 @@ int pick_variant_rules(const ConvArgs& a) {
     return -1;
 }
 
-// Measured choice first (conv_tuned.h: the network's own layer shapes at the tuned device batches, plain layers
-// only - the fused argmax / upsampling launches have one kernel that can serve them), the rules otherwise.
-int pick_variant(const ConvArgs& a, bool rules_only = false) {
+// Measured choice first, the rules otherwise.  Order: a tuning override of this context (tools/tune_in_network.py), the
+// in-network table (conv_tuned_net.h: every layer kind timed INSIDE a forward pass on real activations - a launch whose
+// tensors come from HBM behind other layers ranks the tiles differently from one that re-reads them out of the MALL),
+// the single-layer table (conv_tuned.h: mvlm_conv_bench on idle data, plain layers only).  The fused argmax / upsampling
+// launches have one kernel that can serve them.
+int pick_variant(const mvlm_ctx* ctx, const ConvArgs& a, bool rules_only = false) {
     const int by_rule = pick_variant_rules(a);
-    if (rules_only || MVLM_CONV_TUNED_N == 0 || a.amax_val || a.up_in || a.up_out == 2 || a.ksize == 2 || a.H != a.W)
-        return by_rule;
-    const ConvTuned key = {short(a.ksize), short(a.cin_pad), short(a.cout_pad), short(a.H), short(a.B > 32767 ? 32767 : a.B), 0};
+    if (rules_only || a.amax_val || a.up_in || a.up_out == 2 || a.ksize == 2 || a.H != a.W) return by_rule;
+    const int kind = mvlm_conv_kind(a);
+    if (ctx)
+        for (const ConvOverride& o : ctx->conv_overrides)
+            if (o.ksize == a.ksize && o.cin_pad == a.cin_pad && o.cout_pad == a.cout_pad && o.size == a.H && o.kind == kind) return o.variant;
+    const short batch = short(a.B > 32767 ? 32767 : a.B);
+    if (MVLM_CONV_TUNED_NET_N > 0) {
+        const ConvTunedNet key = {short(a.ksize), short(a.cin_pad), short(a.cout_pad), short(a.H), short(kind), batch, 0};
+        auto less = [](const ConvTunedNet& x, const ConvTunedNet& y) {
+            if (x.ksize != y.ksize) return x.ksize < y.ksize;
+            if (x.cin_pad != y.cin_pad) return x.cin_pad < y.cin_pad;
+            if (x.cout_pad != y.cout_pad) return x.cout_pad < y.cout_pad;
+            if (x.size != y.size) return x.size < y.size;
+            if (x.kind != y.kind) return x.kind < y.kind;
+            return x.batch < y.batch;
+        };
+        const ConvTunedNet* end = MVLM_CONV_TUNED_NET + MVLM_CONV_TUNED_NET_N;
+        const ConvTunedNet* it = std::lower_bound(MVLM_CONV_TUNED_NET, end, key, less);  // smallest tuned batch >= B of this (shape, kind)
+        if (it != end && it->ksize == key.ksize && it->cin_pad == key.cin_pad && it->cout_pad == key.cout_pad && it->size == key.size &&
+            it->kind == key.kind)
+            return it->variant;
+    }
+    if (MVLM_CONV_TUNED_N == 0) return by_rule;
+    const ConvTuned key = {short(a.ksize), short(a.cin_pad), short(a.cout_pad), short(a.H), batch, 0};
     auto less = [](const ConvTuned& x, const ConvTuned& y) {
         if (x.ksize != y.ksize) return x.ksize < y.ksize;
         if (x.cin_pad != y.cin_pad) return x.cin_pad < y.cin_pad;
@@ -155,9 +180,14 @@ const char* mvlm_conv_variant_name_impl(int v) {
     return "?";
 }
 
-bool mvlm_conv_can_pool(const ConvArgs& a) {
-    if (a.up_out || a.amax_val || (a.H & 1) || (a.W & 1)) return false;
-    switch (pick_variant(a) & 255) {
+int mvlm_conv_kind(const ConvArgs& a) { return a.up_out == 1 ? 1 : ((a.pool_out || a.pool_hint) ? 2 : 0); }
+
+bool mvlm_conv_can_pool(const mvlm_ctx* ctx, const ConvArgs& a_in) {
+    if (a_in.up_out || a_in.amax_val || (a_in.H & 1) || (a_in.W & 1)) return false;
+    ConvArgs a = a_in;
+    a.pool_hint = 1;
+    if (ctx && ctx->conv_force_variant >= 0) return mvlm_conv_variant_can_pool(ctx->conv_force_variant);
+    switch (pick_variant(ctx, a) & 255) {
 #define X(id, name, ...)                                                                                   \
     case id: {                                                                                             \
         using V = __VA_ARGS__;                                                                             \
@@ -210,7 +240,7 @@ int mvlm_conv_pair_variant(const ConvArgs& a0, const ConvArgs& a1, int mode) {
     if (a0.B != a1.B) return -1;
     int v = -1;
     if (mode == 2) {
-        for (int cand : {pick_variant(a0), pick_variant(a1), pick_variant_rules(a0), pick_variant_rules(a1)}) {
+        for (int cand : {pick_variant(nullptr, a0), pick_variant(nullptr, a1), pick_variant_rules(a0), pick_variant_rules(a1)}) {
             if (cand < 0) continue;
             const int base = cand & 255, lg = cand >> 8;
             if (pair_variant_serves(base, a0) && pair_variant_serves(base, a1)) {
@@ -282,9 +312,9 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     MVLM_REQUIRE(ctx, !a.out || px * a.out_ctot * (a.up_out ? 4 : 1) < lim, "conv: output exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, a.up_out != 1 || px * a.skip_ctot * 4 < lim, "conv: skip tensor exceeds 32-bit element offsets");
     // conv_force_variant (mvlm_conv_bench only): >= 0 that variant, -2 the rules without the tuned table
-    const int v = ctx->conv_force_variant >= 0 ? ctx->conv_force_variant : pick_variant(a, ctx->conv_force_variant == -2);
+    const int v = ctx->conv_force_variant >= 0 ? ctx->conv_force_variant : pick_variant(ctx, a, ctx->conv_force_variant == -2);
     MVLM_REQUIRE(ctx, v >= 0, "conv: no kernel variant for this shape");
-    MVLM_REQUIRE(ctx, !a.pool_out || mvlm_conv_can_pool(a), "conv: this shape's kernel variant cannot emit the pooled tensor");
+    MVLM_REQUIRE(ctx, !a.pool_out || mvlm_conv_variant_can_pool(v), "conv: this shape's kernel variant cannot emit the pooled tensor");
     MVLM_REQUIRE(ctx, !a.pool_out || px / 4 * a.pool_ctot < lim, "conv: pooled output exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, a.out || a.pool_out || a.amax_val, "conv: no output requested");
     if (variant_out) *variant_out = v;
@@ -299,4 +329,52 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
 #undef X
     }
     return ctx->fail("conv: unreachable variant");
+}
+
+
+// ---- tuning hooks (tools/tune_in_network.py) --------------------------------------------------------------------------------
+// can kernel variant `variant` (>= 256: a split-K variant with its input channels over 2 / 4 workgroups) run a 3x3 layer of
+// this shape and kind?  (kind 2 needs a tile that can emit the pooled tensor; the 80- / 84-row tiles serve conv6 / conv10 only)
+extern "C" int mvlm_conv_variant_serves(int variant, int ksize, int cin_pad, int cout_pad, int size, int kind) {
+    if (variant < 0 || variant >= 1024 || ksize != 3 || kind < 0 || kind > 2) return 0;
+    const int parts = 1 << (variant >> 8);
+    switch (variant & 255) {
+#define X(id, name, ...)                                                                                                     \
+    case id: {                                                                                                               \
+        using V = __VA_ARGS__;                                                                                               \
+        if (V::KS != 3 || V::TAIL16 || V::COUT_T == 96) return 0;                                                            \
+        if (size % V::TW != 0 || size % V::TRI != 0 || cout_pad % V::COUT_T != 0 || cin_pad % V::CK != 0) return 0;          \
+        if (V::SPLITK && cin_pad % 32 != 0) return 0;                                                                        \
+        if (parts > 1 && (!V::SPLITK || cin_pad % (parts * V::CK) != 0 || kind != 0)) return 0;                              \
+        if (kind == 2 && !(!V::SPLITK && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0)) return 0;                           \
+        return 1;                                                                                                            \
+    }
+        MVLM_CONV_VARIANTS(X)
+#undef X
+    }
+    return 0;
+}
+
+// kernel variant for every launch of this (shape, kind) on this context, ahead of all tables; variant < 0 removes the
+// entry, ksize == 0 removes all.  Captured launch graphs are dropped (they encode the kernels).
+extern "C" int mvlm_conv_set_override(mvlm_ctx* ctx, int ksize, int cin_pad, int cout_pad, int size, int kind, int variant) {
+    MVLM_ENTER(ctx);
+    auto& ov = ctx->conv_overrides;
+    if (ksize == 0) {
+        ov.clear();
+    } else {
+        for (size_t i = 0; i < ov.size();)
+            if (ov[i].ksize == ksize && ov[i].cin_pad == cin_pad && ov[i].cout_pad == cout_pad && ov[i].size == size && ov[i].kind == kind)
+                ov.erase(ov.begin() + long(i));
+            else
+                ++i;
+        if (variant >= 0) {
+            MVLM_REQUIRE(ctx, mvlm_conv_variant_serves(variant, ksize, cin_pad, cout_pad, size, kind), "conv_set_override: the variant cannot serve this shape");
+            ov.push_back({short(ksize), short(cin_pad), short(cout_pad), short(size), short(kind), variant});
+        }
+    }
+    for (auto& g : ctx->cnn.graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    ctx->cnn.graphs.clear();
+    return 0;
 }
