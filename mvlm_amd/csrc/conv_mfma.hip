@@ -334,7 +334,8 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
 
 // ---- tuning hooks (tools/tune_in_network.py) --------------------------------------------------------------------------------
 // can kernel variant `variant` (>= 256: a split-K variant with its input channels over 2 / 4 workgroups) run a 3x3 layer of
-// this shape and kind?  (kind 2 needs a tile that can emit the pooled tensor; the 80- / 84-row tiles serve conv6 / conv10 only)
+// this shape and kind?  (kind 2: a tile that cannot pool in its epilogue is followed by the pool kernel; the 80- / 84-row tiles
+// serve conv6 / conv10 only)
 extern "C" int mvlm_conv_variant_serves(int variant, int ksize, int cin_pad, int cout_pad, int size, int kind) {
     if (variant < 0 || variant >= 1024 || ksize != 3 || kind < 0 || kind > 2) return 0;
     const int parts = 1 << (variant >> 8);
@@ -345,8 +346,7 @@ extern "C" int mvlm_conv_variant_serves(int variant, int ksize, int cin_pad, int
         if (V::KS != 3 || V::TAIL16 || V::COUT_T == 96) return 0;                                                            \
         if (size % V::TW != 0 || size % V::TRI != 0 || cout_pad % V::COUT_T != 0 || cin_pad % V::CK != 0) return 0;          \
         if (V::SPLITK && cin_pad % 32 != 0) return 0;                                                                        \
-        if (parts > 1 && (!V::SPLITK || cin_pad % (parts * V::CK) != 0 || kind != 0)) return 0;                              \
-        if (kind == 2 && !(!V::SPLITK && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0)) return 0;                           \
+        if (parts > 1 && (!V::SPLITK || cin_pad % (parts * V::CK) != 0)) return 0;                                           \
         return 1;                                                                                                            \
     }
         MVLM_CONV_VARIANTS(X)

@@ -158,14 +158,17 @@ def write_header(rows):
         table[k] = r
     for k in sorted(table):
         r = table[k]
+        if r["kept"] == r["current"]:
+            continue  # the existing choice stands: the single-layer table / the rules keep answering for this key
         kept_name = r["best_name"] if r["kept"] == r["best"] else r["current_name"]
         note = f"{kept_name} {r['best_us'] if r['kept'] == r['best'] else r['current_us']} us"
         if r["kept"] != r["current"]:
             note += f" (was {r['current_name']} {r['current_us']} us)"
         lines.append(f"    {{{k[0]}, {k[1]}, {k[2]}, {k[3]}, {k[4]}, {k[5]}, {r['kept']}}},  // {note}")
-    if not table:
+    n = sum(1 for ln in lines if ln.startswith("    {"))
+    if n == 0:
         lines.append("    {0, 0, 0, 0, 0, 0, -1},")
-    lines += ["};", f"static const int MVLM_CONV_TUNED_NET_N = {len(table)};", "#endif", ""]
+    lines += ["};", f"static const int MVLM_CONV_TUNED_NET_N = {n};", "#endif", ""]
     HEADER.write_text("\n".join(lines))
     (REPO / "gpurun_out" / "conv_tuned_net.h").write_text("\n".join(lines))
     print(f"wrote {HEADER} ({len(table)} entries)")
