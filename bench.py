@@ -282,7 +282,7 @@ def main():
                          "record the events over the same number of steps right after the timed region")
     ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra pass that measures the opt-in fast precision")
-    ap.add_argument("--precision", default="exact", choices=["exact", "fast"], help=argparse.SUPPRESS)  # experiments: time the fast path as the main loop
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast", "fast16"], help=argparse.SUPPRESS)  # experiments: time the fast path as the main loop
     ap.add_argument("--selection", default="simple", choices=["simple", "moment"],
                     help="heatmap maxima (paulsenpredictor.py:112-158): the argmax pixel (default) or the 31x31 centroid around it - both fused")
     ap.add_argument("--cnn-execution", default="", help=argparse.SUPPRESS)  # "graphs,concurrency" for experiments, e.g. "1,0"
@@ -388,8 +388,8 @@ def main():
         pipe.predictor_2d.set_execution(graphs=bool(g), concurrency=cc)
     if args.selection != "simple" and not fusion_only:
         pipe.predictor_2d.selection_method = args.selection
-    if args.precision == "fast" and not fusion_only:
-        pipe.predictor_2d.set_precision("fast")
+    if args.precision != "exact" and not fusion_only:
+        pipe.predictor_2d.set_precision(args.precision)
         args.no_fast_mode = True
     cnn_ctx = None if fusion_only else pipe.predictor_2d.ctx
     r_ctx = pipe.renderer_3d.ctx
@@ -421,6 +421,8 @@ def main():
         if cnn_ctx is not None:
             n = cnn_ctx.lib.mvlm_cnn_get_profile(cnn_ctx.handle, slot, var, fl, ms, cap)
             for i in range(max(n, 0)):
+                if slot[i] < 0:
+                    continue  # the pool kernel behind a block whose tiles cannot pool (not a convolution)
                 p = prof.setdefault(var[i], [0.0, 0.0, 0])
                 p[0] += fl[i]
                 p[1] += ms[i]
@@ -488,57 +490,69 @@ def main():
     exec_stats = None if fusion_only else pipe.predictor_2d.execution_stats()
 
     # ---- opt-in "fast" precision (bf16x3 split, mvlm_amd/csrc/conv_fast.hip): a separate figure, never `value` ----------
-    fast_mode = None
+    fast_mode = fast16_mode = None
     if not sharded and not fusion_only and not args.no_fast_mode:
         p2 = pipe.predictor_2d
         lm_exact, _ = step()
         images = pipe._buffers["images"]
         max_exact = p2.predict_device(images).clone()
-        p2.set_precision("fast")
-        try:
-            for _ in range(3):  # launch by launch, capture, first replay
+
+        def measure(precision, variant_id, arithmetic):
+            p2.set_precision(precision)
+            try:
+                for _ in range(3):  # launch by launch, capture, first replay
+                    step()
+                barrier()
+                tf0 = time.perf_counter()
+                for _ in range(args.steps):
+                    lm_fast, _ = step()
+                barrier()
+                t_fast = (time.perf_counter() - tf0) / args.steps
+                max_fast = p2.predict_device(images)
+                differ = int((~torch.all(max_fast[:, :, :2] == max_exact[:, :, :2], dim=2)).sum().item())
+                fast_prof = {}
+                set_profiling(1)
                 step()
-            barrier()
-            tf0 = time.perf_counter()
-            for _ in range(args.steps):
-                lm_fast, _ = step()
-            barrier()
-            t_fast = (time.perf_counter() - tf0) / args.steps
-            max_fast = p2.predict_device(images)
-            differ = int((~torch.all(max_fast[:, :, :2] == max_exact[:, :, :2], dim=2)).sum().item())
-            fast_prof = {}
-            set_profiling(1)
-            step()
-            n = cnn_ctx.lib.mvlm_cnn_get_profile(cnn_ctx.handle, slot, var, fl, ms, cap)
-            fast_slots = {}
-            for i in range(max(n, 0)):
-                for q in (fast_prof.setdefault(var[i], [0.0, 0.0, 0]), fast_slots.setdefault((slot[i], var[i]), [0.0, 0.0, 0])):
-                    q[0] += fl[i]
-                    q[1] += ms[i]
-                    q[2] += 1
-            r_ctx.lib.mvlm_render_get_profile(r_ctx.handle, rv, rverts, rtris, rms, 64)
-            set_profiling(0)
-        finally:
-            p2.set_precision("exact")
-        if rank == 0:
-            log("fast precision, conv kernels of one step:")
-            for k, (f, t_ms, cnt) in sorted(fast_prof.items(), key=lambda kv: -kv[1][1]):
-                log(f"  {cnn_ctx.lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt:3d}  {t_ms:8.3f} ms/step  "
-                    f"{f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s (fp32-equivalent)")
-            if os.environ.get("MVLM_BENCH_PER_LAYER"):
-                names = [sl.name for sl in arch.conv_slots(nl, c)]
-                sizes = arch.conv_spatial_sizes()
-                for (sl, v), (f, t_ms, cnt) in sorted(fast_slots.items()):
-                    log(f"    slot {sl:3d} {names[sl]:22s} @{sizes[names[sl]]:3d} {cnn_ctx.lib.mvlm_conv_variant_name(v).decode():22s} "
-                        f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
-        fk = fast_prof.get(62)
-        fast_mode = {"value": round(n_total / t_fast, 2), "unit": "views/s", "ms_per_step": round(1e3 * t_fast, 3),
-                     "arithmetic": "opt-in: 3x3 layers with 16..256 input and >= 64 output channels on 32-pixel rows on bf16x3-split operands "
-                                   "(6 of 9 cross products, v_mfma_f32_32x32x16_bf16, fp32 accumulate); everything else exact fp32",
-                     "argmax_planes_differing_from_exact": differ, "argmax_planes": int(max_exact.shape[0] * max_exact.shape[1]),
-                     "max_landmark_deviation_vs_exact_model_units": round(float(np.abs(lm_fast - lm_exact).max()), 6),
-                     "fast_kernel_launches_per_step": fk[2] if fk else 0,
-                     "fast_kernel_fp32_equivalent_tflops": round(fk[0] / (fk[1] * 1e-3) / 1e12, 1) if fk else None}
+                n = cnn_ctx.lib.mvlm_cnn_get_profile(cnn_ctx.handle, slot, var, fl, ms, cap)
+                fast_slots = {}
+                for i in range(max(n, 0)):
+                    if slot[i] < 0:
+                        continue
+                    for q in (fast_prof.setdefault(var[i], [0.0, 0.0, 0]), fast_slots.setdefault((slot[i], var[i]), [0.0, 0.0, 0])):
+                        q[0] += fl[i]
+                        q[1] += ms[i]
+                        q[2] += 1
+                r_ctx.lib.mvlm_render_get_profile(r_ctx.handle, rv, rverts, rtris, rms, 64)
+                set_profiling(0)
+                still = p2.precision
+            finally:
+                p2.set_precision("exact")
+            if rank == 0:
+                log(f"{precision} precision, conv kernels of one step:")
+                for k, (f, t_ms, cnt) in sorted(fast_prof.items(), key=lambda kv: -kv[1][1]):
+                    log(f"  {cnn_ctx.lib.mvlm_conv_variant_name(k).decode():24s} launches/step {cnt:3d}  {t_ms:8.3f} ms/step  "
+                        f"{f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s (fp32-equivalent)")
+                if os.environ.get("MVLM_BENCH_PER_LAYER"):
+                    names = [sl.name for sl in arch.conv_slots(nl, c)]
+                    sizes = arch.conv_spatial_sizes()
+                    for (sl, v), (f, t_ms, cnt) in sorted(fast_slots.items()):
+                        if sl < 0:
+                            continue
+                        log(f"    slot {sl:3d} {names[sl]:22s} @{sizes[names[sl]]:3d} {cnn_ctx.lib.mvlm_conv_variant_name(v).decode():22s} "
+                            f"{t_ms / cnt * 1e3:9.1f} us/launch  {f / (t_ms * 1e-3) / 1e12:7.2f} TFLOP/s")
+            fk = fast_prof.get(variant_id)
+            return {"value": round(n_total / t_fast, 2), "unit": "views/s", "ms_per_step": round(1e3 * t_fast, 3),
+                    "arithmetic": arithmetic,
+                    "argmax_planes_differing_from_exact": differ, "argmax_planes": int(max_exact.shape[0] * max_exact.shape[1]),
+                    "max_landmark_deviation_vs_exact_model_units": round(float(np.abs(lm_fast - lm_exact).max()), 6),
+                    "fast_kernel_launches_per_step": fk[2] if fk else 0,
+                    "fast_kernel_fp32_equivalent_tflops": round(fk[0] / (fk[1] * 1e-3) / 1e12, 1) if fk else None,
+                    "fell_back": still != precision}
+
+        fast_mode = measure("fast", 62, "opt-in: 3x3 layers with 16..256 input and >= 64 output channels on 32-pixel rows on bf16x3-split operands "
+                                        "(6 of 9 cross products, v_mfma_f32_32x32x16_bf16, fp32 accumulate); everything else exact fp32")
+        fast16_mode = measure("fast16", 61, "opt-in: the same layers on f16x2-split operands (3 of 4 cross products, v_mfma_f32_32x32x16_f16, fp32 "
+                                            "accumulate, per-layer power-of-two weight scale); everything else exact fp32")
     per_rank_ms = None
     if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
@@ -618,7 +632,7 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": ("f32" if args.precision == "exact" else "bf16x3 (opt-in fast precision: NOT the exact path)") if not fusion_only else "f64",
+            "dtype": ("f32" if args.precision == "exact" else ("bf16x3" if args.precision == "fast" else "f16x2") + " (opt-in fast precision: NOT the exact path)") if not fusion_only else "f64",
             "data": "synthetic",
             "config": {"workload": f"{what}: {n_total} views @ 256x256 of one {mesh.n_tris}-triangle textured synthetic "
                                    f"face OBJ, {nl} landmarks" + ("" if fusion_only else f", {c} input channels ({spec['mode']}), seeded random weights"),
@@ -646,6 +660,7 @@ def main():
                                "over the same number of extra steps, + rank skew = max - min of per_rank_ms_per_step)"},
             "cnn_execution": exec_stats,
             "fast_mode": fast_mode,
+            "fast16_mode": fast16_mode,
             "cpu_baseline": cpu,
             "with_ingest": ingest,
         }

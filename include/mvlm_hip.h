@@ -149,7 +149,7 @@ int mvlm_cnn_execution_stats(mvlm_ctx* ctx, int64_t* eager_runs, int64_t* graph_
  *   mvlm_pack_fast_weights: host; w f32[cout][cin][3][3] -> u16 [cin_pad/16][3][3][2][3][cout_pad][8]; returns the element
  *     count (out == NULL: only the count).
  *   mvlm_cnn_load_fast: after mvlm_cnn_load; one blob of packed layers, slot_offsets[n_slots] = u16 offset per conv slot or -1.
- *   mvlm_cnn_set_precision: 0 exact (default), 1 fast.
+ *   mvlm_cnn_set_precision: 0 exact (default), 1 fast (bf16x3), 2 fast16 (f16x2, below).
  *   mvlm_conv2d_fast: test hook like mvlm_conv2d (3x3 only). */
 size_t mvlm_pack_fast_weights(const float* w, int cout, int cin, int cout_pad, int cin_pad, uint16_t* out);
 int mvlm_cnn_load_fast(mvlm_ctx* ctx, const uint16_t* blob_host, size_t n_u16, const int64_t* slot_offsets, int n_slots);
@@ -157,6 +157,21 @@ int mvlm_cnn_set_precision(mvlm_ctx* ctx, int fast);
 int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
                      const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
                      const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev);
+/* Second opt-in form, mvlm_cnn_set_precision(ctx, 2) ("fast16"): the same layers on f16x2-split operands - x = h + l as two
+ * fp16 terms (22 significant bits), the three cross products xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation: 3/16 of the exact path's matrix time.  Per product 3-4 x the error of the bf16x3 form, still of the order of
+ * an fp32 summation's own rounding.  The weights are scaled per layer by a power of two on the host (fp16's exponent is
+ * narrow; the epilogue multiplies by the inverse, exactly); an activation with |x| >= 65520 becomes inf and turns the
+ * pass's maxima non-finite - the Python layer then repeats the pass with the bf16x3 form.
+ *   mvlm_pack_fast_weights16: like mvlm_pack_fast_weights with two splits per operand; *unscale = the inverse scale.
+ *   mvlm_cnn_load_fast16: after mvlm_cnn_load; slot_unscale[n_slots] = the inverse scale per conv slot.
+ *   mvlm_conv2d_fast16: test hook like mvlm_conv2d_fast. */
+size_t mvlm_pack_fast_weights16(const float* w, int cout, int cin, int cout_pad, int cin_pad, uint16_t* out, float* unscale);
+int mvlm_cnn_load_fast16(mvlm_ctx* ctx, const uint16_t* blob_host, size_t n_u16, const int64_t* slot_offsets,
+                         const float* slot_unscale, int n_slots);
+int mvlm_conv2d_fast16(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
+                       const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
+                       const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev);
 /* per-kernel timing of the last mvlm_cnn_* call when profiling is on: fills up to
  * `cap` records of {slot, kernel_variant, flops, ms}; returns the record count. */
 int mvlm_cnn_set_profiling(mvlm_ctx* ctx, int enabled);

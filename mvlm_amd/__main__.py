@@ -35,7 +35,7 @@ def main(argv=None) -> int:
     parser.add_argument("--weights", type=str, default=None,
                         help='checkpoint path, or "synthetic[:seed]" (no checkpoint is reachable offline)')
     parser.add_argument("--device", type=int, default=0)
-    parser.add_argument("--precision", choices=("exact", "fast"), default="exact",
+    parser.add_argument("--precision", choices=("exact", "fast", "fast16"), default="exact",
                         help="exact: fp32 on the matrix cores (default, the parity path); fast: the big 3x3 layers on "
                              "bf16x3-split operands (fp32-accurate, not bit-identical; DESIGN.md 4.1b)")
     parser.add_argument("--batch-scans", type=int, default=1,
@@ -75,7 +75,7 @@ def main(argv=None) -> int:
 
     from . import pipeline
 
-    extra = {"precision": "fast"} if args.precision == "fast" else {}
+    extra = {"precision": args.precision} if args.precision != "exact" else {}
     if args.config is not None:
         from . import config as mvlm_config
 

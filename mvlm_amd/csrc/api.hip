@@ -50,6 +50,7 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
         if (kv.second.first) hipFree(kv.second.first);
     if (ctx->cnn.blob) hipFree(ctx->cnn.blob);
     if (ctx->cnn.fast_blob) hipFree(ctx->cnn.fast_blob);
+    if (ctx->cnn.fast16_blob) hipFree(ctx->cnn.fast16_blob);
     for (int i = 0; i < 2; ++i) {
         if (ctx->kparts_ws[i]) hipFree(ctx->kparts_ws[i]);
         if (ctx->kparts_cnt[i]) hipFree(ctx->kparts_cnt[i]);

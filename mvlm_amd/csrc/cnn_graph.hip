@@ -177,7 +177,8 @@ struct Exec {
         return 0;
     }
     bool runs_fast(int slot, const ConvArgs& a) const {
-        return st.fast && size_t(slot) < st.fast_off.size() && st.fast_off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a);
+        const std::vector<long long>& off = st.fast == 2 ? st.fast16_off : st.fast_off;
+        return st.fast && size_t(slot) < off.size() && off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a);
     }
     // per-launch HIP events (profiling runs only)
     int prof_begin(hipEvent_t& e0, hipEvent_t& e1) {
@@ -203,8 +204,13 @@ struct Exec {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof_begin(e0, e1)) return rc;
         if (runs_fast(slot, a)) {
-            variant = MVLM_CONV_VARIANT_FAST;
-            if (mvlm_launch_conv_fast(ctx, a, st.fast_blob + st.fast_off[size_t(slot)])) return rc = 1;
+            if (st.fast == 2) {
+                variant = MVLM_CONV_VARIANT_FAST16;
+                if (mvlm_launch_conv_fast(ctx, a, st.fast16_blob + st.fast16_off[size_t(slot)], 2, st.fast16_unscale[size_t(slot)])) return rc = 1;
+            } else {
+                variant = MVLM_CONV_VARIANT_FAST;
+                if (mvlm_launch_conv_fast(ctx, a, st.fast_blob + st.fast_off[size_t(slot)])) return rc = 1;
+            }
         } else if (mvlm_launch_conv(ctx, a, &variant)) {
             return rc = 1;
         }
@@ -398,7 +404,7 @@ struct Exec {
 
     // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
     bool pool_fusable(int slot, const Tensor& x, ConvArgs a, int S) {
-        if (st.fast) return false;  // the bf16x3 kernel has no pooled output: the pool kernel follows the block
+        if (st.fast) return false;  // the split-operand kernels have no pooled output: the pool kernel follows the block
         const int32_t* r = d(slot);
         a.cin = r[1];
         a.cout = r[2];
@@ -799,6 +805,12 @@ extern "C" int mvlm_cnn_load(mvlm_ctx* ctx, const float* blob_host, size_t n_flo
         (void)hipFree(st.fast_blob);
         st.fast_blob = nullptr;
     }
+    st.fast16_off.clear();
+    st.fast16_unscale.clear();
+    if (st.fast16_blob) {
+        (void)hipFree(st.fast16_blob);
+        st.fast16_blob = nullptr;
+    }
     for (auto& g : st.graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);  // captured launches point into the old weight blob
     st.graphs.clear();
@@ -928,7 +940,7 @@ extern "C" int mvlm_cnn_load_fast(mvlm_ctx* ctx, const uint16_t* blob_host, size
     for (auto& g : st.graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);
     st.graphs.clear();
-    st.fast = 0;
+    if (st.fast == 1) st.fast = 0;
     if (st.fast_blob) {
         MVLM_CHECK_HIP(ctx, hipFree(st.fast_blob));
         st.fast_blob = nullptr;
@@ -939,11 +951,43 @@ extern "C" int mvlm_cnn_load_fast(mvlm_ctx* ctx, const uint16_t* blob_host, size
     return 0;
 }
 
+// the f16x2 form's weights (mvlm_pack_fast_weights16): one blob, per conv slot the u16 offset (-1: stays exact) and the inverse scale
+extern "C" int mvlm_cnn_load_fast16(mvlm_ctx* ctx, const uint16_t* blob_host, size_t n_u16, const int64_t* slot_offsets,
+                                    const float* slot_unscale, int n_slots) {
+    MVLM_ENTER(ctx);
+    CnnState& st = ctx->cnn;
+    MVLM_REQUIRE(ctx, st.loaded, "cnn_load_fast16: mvlm_cnn_load comes first");
+    MVLM_REQUIRE(ctx, blob_host && slot_offsets && slot_unscale && n_u16 > 0 && size_t(n_slots) * MVLM_CONV_DESC_INTS == st.desc.size(),
+                 "cnn_load_fast16: bad arguments");
+    for (int s = 0; s < n_slots; ++s) {
+        if (slot_offsets[s] < 0) continue;
+        const int32_t* r = &st.desc[size_t(s) * MVLM_CONV_DESC_INTS];
+        MVLM_REQUIRE(ctx, r[0] && r[3] == 3 && mvlm_fast_channels_ok(r[1], r[2]), "cnn_load_fast16: slot is not a fast-eligible 3x3 layer");
+        const size_t need = size_t(mvlm_fast_cin_pad(r[1]) / 16) * 9 * 2 * 2 * size_t(mvlm_fast_cout_pad(r[2])) * 8;
+        MVLM_REQUIRE(ctx, slot_offsets[s] % 8 == 0 && size_t(slot_offsets[s]) + need <= n_u16, "cnn_load_fast16: offset out of range");
+        MVLM_REQUIRE(ctx, slot_unscale[s] > 0.f && slot_unscale[s] < 3.0e38f, "cnn_load_fast16: bad inverse scale");
+    }
+    for (auto& g : st.graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    st.graphs.clear();
+    if (st.fast == 2) st.fast = 0;
+    if (st.fast16_blob) {
+        MVLM_CHECK_HIP(ctx, hipFree(st.fast16_blob));
+        st.fast16_blob = nullptr;
+    }
+    MVLM_CHECK_HIP(ctx, hipMalloc(&st.fast16_blob, n_u16 * sizeof(uint16_t)));
+    MVLM_CHECK_HIP(ctx, hipMemcpy(st.fast16_blob, blob_host, n_u16 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    st.fast16_off.assign(slot_offsets, slot_offsets + n_slots);
+    st.fast16_unscale.assign(slot_unscale, slot_unscale + n_slots);
+    return 0;
+}
+
 extern "C" int mvlm_cnn_set_precision(mvlm_ctx* ctx, int fast) {
     MVLM_ENTER(ctx);
     CnnState& st = ctx->cnn;
-    MVLM_REQUIRE(ctx, fast == 0 || fast == 1, "cnn_set_precision: 0 (exact fp32) or 1 (bf16x3 split on the eligible layers)");
-    MVLM_REQUIRE(ctx, !fast || st.fast_blob, "cnn_set_precision: mvlm_cnn_load_fast has not been called");
+    MVLM_REQUIRE(ctx, fast >= 0 && fast <= 2, "cnn_set_precision: 0 (exact fp32), 1 (bf16x3 split) or 2 (f16x2 split on the eligible layers)");
+    MVLM_REQUIRE(ctx, fast != 1 || st.fast_blob, "cnn_set_precision: mvlm_cnn_load_fast has not been called");
+    MVLM_REQUIRE(ctx, fast != 2 || st.fast16_blob, "cnn_set_precision: mvlm_cnn_load_fast16 has not been called");
     if (fast != st.fast) {  // captured graphs encode the kernels
         for (auto& g : st.graphs)
             if (g.exec) hipGraphExecDestroy(g.exec);

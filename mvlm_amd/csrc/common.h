@@ -112,6 +112,7 @@ struct ConvArgs {
     // pool_out is [B][pool_ctot][H/2][W/2]; `out` may be null when only the pooled tensor is consumed
     float* pool_out = nullptr;
     int pool_ctot = 0, pool_coff = 0;
+    float fast_unscale = 1.f;  // f16x2 kernel only: inverse of the power-of-two scale its packed weights carry
     int pool_hint = 0;  // the caller wants the pooled tensor too (set for the variant choice, before pool_out is decided)
     // -DMVLM_CONV_TIMING builds only (tools/conv_phase_timing.py): u64[4] = summed cycles of wave 0 in
     // prologue / K loop / epilogue, number of workgroups
@@ -167,7 +168,10 @@ struct CnnState {
     // opt-in "fast" precision (conv_fast.hip): bf16x3-split weights of the eligible 3x3 layers, per conv slot
     unsigned short* fast_blob = nullptr;
     std::vector<long long> fast_off;   // u16 element offset per slot, -1 = the layer stays on the exact kernel
-    int fast = 0;                      // 1: eligible layers run on the bf16x3 kernel
+    int fast = 0;                      // 1: eligible layers run on the bf16x3 kernel, 2: on the f16x2 kernel
+    unsigned short* fast16_blob = nullptr;   // the f16x2 form's packed weights, offsets and per-layer inverse scales
+    std::vector<long long> fast16_off;
+    std::vector<float> fast16_unscale;
     std::vector<CnnGraphEntry> graphs;
     long graph_replays = 0, graph_captures = 0, eager_runs = 0, graph_failures = 0;
 };
@@ -298,8 +302,9 @@ inline bool mvlm_fast_channels_ok(int cin, int cout) {
     return cin >= 16 && cin <= 256 && cout > 0 && cout * 8 >= mvlm_fast_cout_pad(cout) * 5;
 }
 bool mvlm_conv_fast_ok(const ConvArgs& a);
-int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev);
-constexpr int MVLM_CONV_VARIANT_FAST = 62;  // id reported for launches of the bf16x3 kernel
+int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev, int splits = 3, float unscale = 1.f);
+constexpr int MVLM_CONV_VARIANT_FAST = 62;    // id reported for launches of the bf16x3 kernel
+constexpr int MVLM_CONV_VARIANT_FAST16 = 61;  // ... of the f16x2 kernel
 
 // small kernels (misc.hip)
 int mvlm_launch_pack_input(mvlm_ctx* ctx, const float* images, int n, const int* sel4, int c, float* out);

@@ -22,16 +22,28 @@
 //   * the consumer-side BatchNorm + ReLU is applied in fp32 before the split, zero padding after it.
 //   * weights are split and laid out on the host ([chunk][tap row][tap][k-half][split][cout_pad][8], mvlm_pack_fast_weights)
 //     so that staging W is a linear 16-byte copy.
+// Second form, NS = 2 ("fast16"): every operand as TWO fp16 terms, x = h + l (h = fp16(x), l = fp16(x - h): 22 significant
+// bits), the product as the three cross terms xh*wh + xh*wl + xl*wh (dropped: xl*wl <= 2^-22 relative) on
+// v_mfma_f32_32x32x16_f16 - half the matrix work of the bf16x3 form (3/16 of the exact path's).  fp16 products of 11-bit
+// mantissas are exact in fp32, so the error per product is the operands' 2^-22 representation error plus the dropped
+// term: 3-4 x that of bf16x3, still below what the order of an fp32 summation over K = 2304 terms moves.  fp16 has a
+// narrow exponent: the weights are scaled by a power of two per layer on the host (largest |w| into [2^13, 2^14); the
+// epilogue multiplies by the inverse, exactly), activations go in as they are - |x| >= 65520 becomes +-inf and poisons
+// everything downstream with inf / NaN (the caller sees non-finite maxima and falls back, pipeline / predictor), small
+// activations lose nothing that matters: |x - (h + l)| <= max(2^-22 |x|, 2^-25).
 // Layers it serves: 3x3, input channels a multiple of 16, output channels a multiple of 64, width a multiple of 32,
 // height of 8, plain NCHW output with optional bias / post-BN+ReLU / raw copy / one residual.  Everything else (and
 // every layer in the default "exact" precision) runs on conv_mfma_kernel.
+#include <cmath>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 namespace {
@@ -64,28 +76,58 @@ __device__ __forceinline__ void split3(float x, unsigned* h, unsigned* m, unsign
     *l = bf16_bits(r2);
 }
 
+// x -> (h, l) fp16 bit patterns with |x - (h + l)| <= max(2^-22 |x|, 2^-25); |x| >= 65520 gives h = +-inf
+__device__ __forceinline__ void split2(float x, unsigned* h, unsigned* l) {
+    const _Float16 hh = static_cast<_Float16>(x);  // round to nearest even (v_cvt_f16_f32)
+    const float r = x - static_cast<float>(hh);
+    const _Float16 ll = static_cast<_Float16>(r);
+    *h = __builtin_bit_cast(unsigned short, hh);
+    *l = __builtin_bit_cast(unsigned short, ll);
+}
+
+// the arithmetic of a split: NS terms per operand, the cross terms (weight term, activation term) smallest first
+template <int NS>
+struct Split;
+template <>
+struct Split<3> {
+    using frag = bf16x8;
+    static constexpr int NTERMS = 6;
+    static constexpr int WS[6] = {0, 2, 1, 0, 1, 0}, XS[6] = {2, 0, 1, 1, 0, 0};  // (h,l) (l,h) (m,m) | (h,m) (m,h) | (h,h)
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Split<2> {
+    using frag = f16x8;
+    static constexpr int NTERMS = 3;
+    static constexpr int WS[3] = {0, 1, 0}, XS[3] = {1, 0, 0};  // (h,l) (l,h) | (h,h)
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 // COUT_T output channels x (TRI rows x 32 pixels); 8 waves = 2 channel halves x 4 groups of TRI / 4 rows
-template <int COUT_T, int TRI>
+template <int COUT_T, int TRI, int NS = 3>
 struct FastCfg {
     static constexpr int MT = COUT_T / 64;               // 32-row MFMA tiles per wave (channels)
     static constexpr int NT = TRI / 4;                    // 32-pixel row segments per wave
     static constexpr int PH = TRI + 2, NPIX = FT_PW * PH;  // haloed tile
-    static constexpr int X_BYTES = 2 * 3 * NPIX * 16;      // [k-half][split][pixel][8 ch]
-    static constexpr int W_BYTES = 3 * 2 * 3 * COUT_T * 16;  // one tap row: [tap][k-half][split][cout][8 ch]
+    static constexpr int X_BYTES = 2 * NS * NPIX * 16;      // [k-half][split][pixel][8 ch]
+    static constexpr int W_BYTES = 3 * 2 * NS * COUT_T * 16;  // one tap row: [tap][k-half][split][cout][8 ch]
     static constexpr int W_ITEMS = W_BYTES / 16, W_ITERS = (W_ITEMS + FT_THREADS - 1) / FT_THREADS;
     static constexpr int X_ITEMS = 2 * NPIX, X_ITERS = (X_ITEMS + FT_THREADS - 1) / FT_THREADS;
-    static constexpr int TAP_MFMAS = 6 * MT * NT;          // per tap and wave
+    static constexpr int TAP_MFMAS = Split<NS>::NTERMS * MT * NT;  // per tap and wave
     static constexpr size_t LDS = size_t(2) * X_BYTES + size_t(2) * W_BYTES + 2 * 256 * sizeof(float);
     static_assert(LDS <= 160 * 1024, "stages must fit the CU's LDS");
-    static_assert(TAP_MFMAS == 24, "the staging schedule below is written for 24 MFMAs per tap");
+    static_assert(TAP_MFMAS == (NS == 3 ? 24 : 12), "the staging schedules below are written for 24 (bf16x3) / 12 (f16x2) MFMAs per tap");
     static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
 };
 
 // GEN: the rarely needed parts (input channels that do not fill the last chunk, a second residual) are compiled in
-template <int COUT_T, int TRI, bool GEN>
-__global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvArgs a, const unsigned short* __restrict__ wq,
-                                                                   const int tiles_x, const int tiles_y, const int cout_tiles) {
-    using C = FastCfg<COUT_T, TRI>;
+template <int COUT_T, int TRI, bool GEN, int NS>
+__global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArgs a, const unsigned short* __restrict__ wq,
+                                                                  const int tiles_x, const int tiles_y, const int cout_tiles) {
+    using C = FastCfg<COUT_T, TRI, NS>;
+    using SP = Split<NS>;
+    using frag_t = typename SP::frag;
+    constexpr int TAPM = C::TAP_MFMAS;
     constexpr int MT = C::MT, NT = C::NT, NPIX = C::NPIX, X_BYTES = C::X_BYTES, W_BYTES = C::W_BYTES;
     constexpr int W_ITEMS = C::W_ITEMS, W_ITERS = C::W_ITERS, X_ITEMS = C::X_ITEMS, X_ITERS = C::X_ITERS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fast[];
@@ -124,7 +166,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         const int y = y0 + yy - 1, x = x0 + xx - 1;
         const bool ok = e < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
         xoff[i] = ok ? (unsigned(b0 * a.in_ctot + a.in_coff + 8 * kh) * HW + unsigned(y * W + x)) : 0xFFFFFFFFu;
-        xdst[i] = e < X_ITEMS ? (kh * 3 * NPIX + p) * 16 : -1;
+        xdst[i] = e < X_ITEMS ? (kh * NS * NPIX + p) * 16 : -1;
         xkh[i] = kh;
     }
     // W: item f -> segment (tap, kh, split) and output channel c of the tile; linear in the host layout
@@ -135,10 +177,10 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         const int seg = f / COUT_T, c = f - seg * COUT_T;
         wsrc[i] = f < W_ITEMS ? unsigned((seg * a.cout_pad + co0 + c) * 8) : 0xFFFFFFFFu;
     }
-    const size_t w_block = size_t(18) * a.cout_pad * 8;  // u16 elements of one (chunk, tap row) block
+    const size_t w_block = size_t(6 * NS) * a.cout_pad * 8;  // u16 elements of one (chunk, tap row) block
 
     float xv[X_ITERS][8];      // the next chunk's activations, in flight / waiting for their split
-    unsigned xq[3][4];         // one item's eight channels as bf16 pairs, per split
+    unsigned xq[NS][4];        // one item's eight channels as 16-bit pairs, per split
     u32x4 wv[W_ITERS];         // the next tap row's weights
 
     // ---- staging micro-operations (each one small enough for the shadow of one or two MFMAs) --------------------------
@@ -179,11 +221,14 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
             float v = xv[i][2 * jp + k];
             if (has_bn) v = fmaxf(fmaf(v, k ? sc.y : sc.x, k ? sh.y : sh.x), 0.f);
             v = inside && (!partial_cin || c + k < a.cin) ? v : 0.f;  // zero padding after the activation; channels past cin
-            split3(v, &h[k], &m[k], &l[k]);
+            if constexpr (NS == 3)
+                split3(v, &h[k], &m[k], &l[k]);
+            else
+                split2(v, &h[k], &l[k]);
         }
         xq[0][jp] = h[0] | (h[1] << 16);
-        xq[1][jp] = m[0] | (m[1] << 16);
-        xq[2][jp] = l[0] | (l[1] << 16);
+        if constexpr (NS == 3) xq[1][jp] = m[0] | (m[1] << 16);
+        xq[NS - 1][jp] = l[0] | (l[1] << 16);
     };
     auto store_x = [&](auto ic, auto sc, int chunk) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, sp = decltype(sc)::value;
@@ -199,7 +244,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
     // all of item i at once (prologue)
     auto stage_item = [&](auto ic, int chunk) __attribute__((always_inline)) {
         static_for<0, 4>([&](auto jc) { convert_pair(ic, jc, chunk); });
-        static_for<0, 3>([&](auto sc) { store_x(ic, sc, chunk); });
+        static_for<0, NS>([&](auto sc) { store_x(ic, sc, chunk); });
     };
 
     // ---- accumulators and per-lane LDS offsets ----------------------------------------------------------------------
@@ -213,11 +258,11 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
     // B fragment of pixel row n of this wave, tap (dy, dx): haloed pixel ((NT wn + n + dy) * PW + l31 + dx), k-half = half
     int boff[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) boff[n] = (half * 3 * NPIX + (NT * wn + n) * FT_PW + l31) * 16;
+    for (int n = 0; n < NT; ++n) boff[n] = (half * NS * NPIX + (NT * wn + n) * FT_PW + l31) * 16;
     // A fragment of MFMA tile m: output channel wm * 32 MT + 32 m + l31, k-half = half
     int aoff[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) aoff[m] = (half * 3 * COUT_T + wm * 32 * MT + 32 * m + l31) * 16;
+    for (int m = 0; m < MT; ++m) aoff[m] = (half * NS * COUT_T + wm * 32 * MT + 32 * m + l31) * 16;
 
     // ---- prologue: BatchNorm table, chunk 0's activations, unit 0's weights ----------------------------------------------
     if (has_bn)
@@ -246,7 +291,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         const bool more_w = u + 1 < 3 * n_chunks, more_x = chunk + 1 < n_chunks;
         const unsigned char* const xs = sX + (chunk & 1) * X_BYTES;
         const unsigned char* const ws = sW + (u & 1) * W_BYTES;
-        bf16x8 af[MT][3], bf[NT][3];
+        frag_t af[MT][NS], bf[NT][NS];
         static_for<0, 3>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int poff = (ROW * FT_PW + t) * 16;  // tap (ROW, t): dy = ROW, dx = t in the haloed tile
@@ -254,20 +299,19 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
             if constexpr (t == 0)
 #endif
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
+            for (int sp = 0; sp < NS; ++sp) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    af[m][sp] = *reinterpret_cast<const bf16x8*>(ws + ((t * 6 + sp) * COUT_T) * 16 + aoff[m]);
+                    af[m][sp] = *reinterpret_cast<const frag_t*>(ws + ((t * 2 * NS + sp) * COUT_T) * 16 + aoff[m]);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    bf[n][sp] = *reinterpret_cast<const bf16x8*>(xs + sp * NPIX * 16 + boff[n] + poff);
+                    bf[n][sp] = *reinterpret_cast<const frag_t*>(xs + sp * NPIX * 16 + boff[n] + poff);
             }
-            // six cross terms, smallest first: (w, x) = (h,l) (l,h) (m,m) | (h,m) (m,h) | (h,h)
-            constexpr int WS[6] = {0, 2, 1, 0, 1, 0}, XS[6] = {2, 0, 1, 1, 0, 0};
-            static_for<0, 24>([&](auto ic) {
-                constexpr int i = decltype(ic)::value, q = 24 * t + i;
+            // the cross terms, smallest first (Split<NS>)
+            static_for<0, TAPM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, q = TAPM * t + i;
                 constexpr int p = i / (MT * NT), mn = i % (MT * NT), m = mn / NT, n = mn % NT;
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][WS[p]], bf[n][XS[p]], acc[m][n], 0, 0, 0);
+                acc[m][n] = SP::mfma(af[m][SP::WS[p]], bf[n][SP::XS[p]], acc[m][n]);
                 // ---- side work of slot q ----
 #if defined(MVLM_FAST_ABLATE_NO_STAGING)  // timing experiment only: wrong results
                 if constexpr (q < 0) {
@@ -280,31 +324,41 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
                 if constexpr (q == 1 && ROW == 0) {
                     if (more_x) load_x(chunk + 1);
                 }
-                if constexpr (q >= 24 && q < 24 + 4 * W_ITERS && (q - 24) % 4 == 0) {
-                    if (more_w) store_w(std::integral_constant<int, (q - 24) / 4>{}, u + 1);
+                // slot tables: bf16x3 has 72 slots per unit, f16x2 has 36 - the same micro-operations (one split fewer) at
+                // half the distance.  W stores in tap 1; item 0 during ROW 1; items 1 and 2 during ROW 2; an item's splits are
+                // stored after its four channel pairs have been converted, the next item's conversion starts after that.
+                constexpr int WQ0 = NS == 3 ? 24 : 12, WQS = NS == 3 ? 4 : 2;
+                if constexpr (q >= WQ0 && q < WQ0 + WQS * W_ITERS && (q - WQ0) % WQS == 0) {
+                    if (more_w) store_w(std::integral_constant<int, (q - WQ0) / WQS>{}, u + 1);
                 }
+                constexpr int C0 = NS == 3 ? 2 : 1, C0S = NS == 3 ? 6 : 3;      // ROW 1, item 0: pairs at C0 + C0S j
+                constexpr int S0 = NS == 3 ? 44 : 20, S0S = NS == 3 ? 6 : 4;    //               stores at S0 + S0S sp
+                constexpr int C1 = NS == 3 ? 2 : 1, C1S = NS == 3 ? 4 : 2;      // ROW 2, item 1
+                constexpr int S1 = NS == 3 ? 18 : 9, S1S = NS == 3 ? 2 : 1;
+                constexpr int C2 = NS == 3 ? 28 : 18, C2S = NS == 3 ? 4 : 2;    // ROW 2, item 2
+                constexpr int S2 = NS == 3 ? 60 : 28, S2S = NS == 3 ? 4 : 2;
                 if constexpr (ROW == 1) {
-                    if constexpr (q == 2 || q == 8 || q == 14 || q == 20) {
-                        if (more_x) convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - 2) / 6>{}, chunk + 1);
+                    if constexpr (q >= C0 && q < C0 + 4 * C0S && (q - C0) % C0S == 0) {
+                        if (more_x) convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - C0) / C0S>{}, chunk + 1);
                     }
-                    if constexpr (q == 44 || q == 50 || q == 56) {
-                        if (more_x) store_x(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - 44) / 6>{}, chunk + 1);
+                    if constexpr (q >= S0 && q < S0 + NS * S0S && (q - S0) % S0S == 0) {
+                        if (more_x) store_x(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - S0) / S0S>{}, chunk + 1);
                     }
                 }
                 if constexpr (ROW == 2 && X_ITERS >= 2) {
-                    if constexpr (q == 2 || q == 6 || q == 10 || q == 14) {
-                        if (more_x) convert_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - 2) / 4>{}, chunk + 1);
+                    if constexpr (q >= C1 && q < C1 + 4 * C1S && (q - C1) % C1S == 0) {
+                        if (more_x) convert_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - C1) / C1S>{}, chunk + 1);
                     }
-                    if constexpr (q == 18 || q == 20 || q == 22) {
-                        if (more_x) store_x(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - 18) / 2>{}, chunk + 1);
+                    if constexpr (q >= S1 && q < S1 + NS * S1S && (q - S1) % S1S == 0) {
+                        if (more_x) store_x(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - S1) / S1S>{}, chunk + 1);
                     }
                 }
                 if constexpr (ROW == 2 && X_ITERS >= 3) {
-                    if constexpr (q == 28 || q == 32 || q == 36 || q == 40) {
-                        if (more_x) convert_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - 28) / 4>{}, chunk + 1);
+                    if constexpr (q >= C2 && q < C2 + 4 * C2S && (q - C2) % C2S == 0) {
+                        if (more_x) convert_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - C2) / C2S>{}, chunk + 1);
                     }
-                    if constexpr (q == 60 || q == 64 || q == 68) {
-                        if (more_x) store_x(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - 60) / 4>{}, chunk + 1);
+                    if constexpr (q >= S2 && q < S2 + NS * S2S && (q - S2) % S2S == 0) {
+                        if (more_x) store_x(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - S2) / S2S>{}, chunk + 1);
                     }
                 }
                 }
@@ -353,7 +407,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    float v = acc[m][n][r] + bias;
+                    float v = (NS == 2 ? acc[m][n][r] * a.fast_unscale : acc[m][n][r]) + bias;  // f16x2: weights carry a power-of-two scale
                     if (post) v = fmaxf(fmaf(v, ps, pt), 0.f);
                     if (RAW) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix[n]] = v;
                     if constexpr (RES) v += resv[r][n];
@@ -383,22 +437,29 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_bf16x3_kernel(const ConvAr
         epilogue(F_{}, F_{}, std::integral_constant<int, 3>{});
 }
 
-template <int COUT_T, int TRI, bool GEN>
+template <int COUT_T, int TRI, bool GEN, int NS>
 int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
-    using C = FastCfg<COUT_T, TRI>;
-    const int bit = 60 + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0);
+    using C = FastCfg<COUT_T, TRI, NS>;
+    const int bit = (NS == 3 ? 60 : 56) + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0);
     if (!((ctx->conv_attr_mask >> bit) & 1ull)) {
-        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<COUT_T, TRI, GEN>),
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<COUT_T, TRI, GEN, NS>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS)));
         ctx->conv_attr_mask |= 1ull << bit;
     }
     const int tiles_x = a.W / FT_TW, tiles_y = a.H / TRI, cout_tiles = a.cout_pad / COUT_T;
     const long nblk = long(tiles_x) * tiles_y * a.B * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv_fast: bad grid");
-    hipLaunchKernelGGL((conv_bf16x3_kernel<COUT_T, TRI, GEN>), dim3((unsigned)nblk), dim3(FT_THREADS), C::LDS, ctx->cur_stream(), a, wq,
+    hipLaunchKernelGGL((conv_split_kernel<COUT_T, TRI, GEN, NS>), dim3((unsigned)nblk), dim3(FT_THREADS), C::LDS, ctx->cur_stream(), a, wq,
                        tiles_x, tiles_y, cout_tiles);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
+}
+
+template <int NS>
+int launch_fast_ns(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev) {
+    if (a.cin != a.cin_pad || a.res2)
+        return a.cout_pad % 128 == 0 ? launch_fast<128, 8, true, NS>(ctx, a, wq_dev) : launch_fast<64, 16, true, NS>(ctx, a, wq_dev);
+    return a.cout_pad % 128 == 0 ? launch_fast<128, 8, false, NS>(ctx, a, wq_dev) : launch_fast<64, 16, false, NS>(ctx, a, wq_dev);
 }
 
 }  // namespace
@@ -411,16 +472,16 @@ bool mvlm_conv_fast_ok(const ConvArgs& a) {
     return a.W % FT_TW == 0 && a.H % rows == 0 && !a.up_in && !a.up_out && !a.skip && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
 }
 
-int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& exact, const unsigned short* wq_dev) {
-    MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(exact) && wq_dev, "conv_fast: launch not eligible");
+// splits: 3 = bf16x3 ("fast"), 2 = f16x2 ("fast16": the weights carry the power-of-two scale 1 / unscale)
+int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& exact, const unsigned short* wq_dev, int splits, float unscale) {
+    MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(exact) && wq_dev && (splits == 3 || splits == 2), "conv_fast: launch not eligible");
     ConvArgs a = exact;  // the split weights carry their own paddings
     a.cin_pad = mvlm_fast_cin_pad(a.cin);
     a.cout_pad = mvlm_fast_cout_pad(a.cout);
+    a.fast_unscale = unscale;
     const double px = double(a.B) * a.H * a.W, lim = 4294967295.0;
     MVLM_REQUIRE(ctx, px * a.in_ctot < lim, "conv_fast: input tensor exceeds 32-bit element offsets (lower the batch)");
-    if (a.cin != a.cin_pad || a.res2)
-        return a.cout_pad % 128 == 0 ? launch_fast<128, 8, true>(ctx, a, wq_dev) : launch_fast<64, 16, true>(ctx, a, wq_dev);
-    return a.cout_pad % 128 == 0 ? launch_fast<128, 8, false>(ctx, a, wq_dev) : launch_fast<64, 16, false>(ctx, a, wq_dev);
+    return splits == 3 ? launch_fast_ns<3>(ctx, a, wq_dev) : launch_fast_ns<2>(ctx, a, wq_dev);
 }
 
 // ---- host: split + lay out the weights of one 3x3 convolution -----------------------------------------------------------
@@ -462,17 +523,70 @@ extern "C" size_t mvlm_pack_fast_weights(const float* w, int cout, int cin, int 
     return total;
 }
 
+// The same for the f16x2 form: w * 2^s as two fp16 terms, s chosen so that the layer's largest |w| lies in [2^13, 2^14)
+// (the low term of a weight is then a normal fp16 number down to |w| = 2^-9 of the largest); *unscale = 2^-s.
+// u16 [cin_pad/16][tap row 3][tap 3][k-half 2][split 2][cout_pad][8]; returns the element count.
+static inline unsigned short host_f16(float x) {
+    const _Float16 h = static_cast<_Float16>(x);  // round to nearest even
+    unsigned short b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+static inline float host_f16_value(unsigned short b) {
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return static_cast<float>(h);
+}
+
+extern "C" size_t mvlm_pack_fast_weights16(const float* w, int cout, int cin, int cout_pad, int cin_pad, uint16_t* out, float* unscale) {
+    if (!w || cout <= 0 || cin <= 0 || cout_pad < cout || cin_pad < cin || cin_pad % 16 != 0) return 0;
+    const size_t total = size_t(cin_pad / 16) * 9 * 2 * 2 * cout_pad * 8;
+    if (!out) return total;
+    float amax = 0.f;
+    for (size_t i = 0; i < size_t(cout) * cin * 9; ++i) {
+        const float v = fabsf(w[i]);
+        if (!(v <= 3.0e38f)) return 0;  // NaN / inf weights
+        amax = v > amax ? v : amax;
+    }
+    int s = 0;
+    if (amax > 0.f) {
+        int e = 0;
+        (void)frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+        s = 14 - e;              // amax * 2^s in [2^13, 2^14)
+        s = s > 100 ? 100 : (s < -100 ? -100 : s);
+    }
+    if (unscale) *unscale = ldexpf(1.f, -s);
+    memset(out, 0, total * sizeof(uint16_t));
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tap = 0; tap < 9; ++tap) {
+                const float x = ldexpf(w[(size_t(co) * cin + ci) * 9 + tap], s);
+                const unsigned short h = host_f16(x);
+                const unsigned short l = host_f16(x - host_f16_value(h));
+                const int chunk = ci / 16, kh = (ci % 16) / 8, j = ci % 8, row = tap / 3, t = tap % 3;
+                const unsigned short parts[2] = {h, l};
+                for (int sp = 0; sp < 2; ++sp) {
+                    const size_t idx = ((((size_t(chunk) * 3 + row) * 3 + t) * 2 + kh) * 2 + sp) * cout_pad * 8 + size_t(co) * 8 + j;
+                    out[idx] = parts[sp];
+                }
+            }
+    return total;
+}
+
 // ---- single convolution through the fast kernel (test hook, mirrors mvlm_conv2d) ---------------------------------------
-extern "C" int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
-                                const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
-                                const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev) {
-    MVLM_ENTER(ctx);
+static int conv2d_fast_impl(mvlm_ctx* ctx, int splits, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
+                            const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
+                            const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev) {
     MVLM_REQUIRE(ctx, x_dev && w_host && y_dev, "conv2d_fast: null pointer");
     MVLM_REQUIRE(ctx, mvlm_fast_channels_ok(cin, cout), "conv2d_fast: channel counts outside what the fast kernel serves");
     const int cin_pad = mvlm_fast_cin_pad(cin), cout_pad = mvlm_fast_cout_pad(cout);
-    std::vector<uint16_t> wq(mvlm_pack_fast_weights(w_host, cout, cin, cout_pad, cin_pad, nullptr));
-    MVLM_REQUIRE(ctx, !wq.empty() && mvlm_pack_fast_weights(w_host, cout, cin, cout_pad, cin_pad, wq.data()) == wq.size(),
-                 "conv2d_fast: weight packing failed");
+    float unscale = 1.f;
+    auto pack = [&](uint16_t* out) {
+        return splits == 3 ? mvlm_pack_fast_weights(w_host, cout, cin, cout_pad, cin_pad, out)
+                           : mvlm_pack_fast_weights16(w_host, cout, cin, cout_pad, cin_pad, out, &unscale);
+    };
+    std::vector<uint16_t> wq(pack(nullptr));
+    MVLM_REQUIRE(ctx, !wq.empty() && pack(wq.data()) == wq.size(), "conv2d_fast: weight packing failed");
     std::vector<float> vec(size_t(2) * cin_pad + size_t(3) * cout_pad, 0.f);
     auto fill = [&](size_t off, const float* src, int n) {
         if (src) memcpy(vec.data() + off, src, size_t(n) * sizeof(float));
@@ -507,7 +621,23 @@ extern "C" int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, in
     a.res1_ctot = cout;
     a.out = y_dev;
     a.out_ctot = cout;
-    if (mvlm_launch_conv_fast(ctx, a, dq)) return 1;
+    if (mvlm_launch_conv_fast(ctx, a, dq, splits, unscale)) return 1;
     MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+extern "C" int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
+                                const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
+                                const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev) {
+    MVLM_ENTER(ctx);
+    return conv2d_fast_impl(ctx, 3, x_dev, batch, cin, h, w, w_host, cout, bias_host, pre_scale_host, pre_shift_host, post_scale_host,
+                            post_shift_host, r_dev, y_dev);
+}
+
+extern "C" int mvlm_conv2d_fast16(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
+                                  const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
+                                  const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev) {
+    MVLM_ENTER(ctx);
+    return conv2d_fast_impl(ctx, 2, x_dev, batch, cin, h, w, w_host, cout, bias_host, pre_scale_host, pre_shift_host, post_scale_host,
+                            post_shift_host, r_dev, y_dev);
 }

@@ -151,6 +151,7 @@ int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt) {
 
 const char* mvlm_conv_variant_name_impl(int v) {
     if (v == MVLM_CONV_VARIANT_FAST) return "conv3x3_bf16x3_t8x32";
+    if (v == MVLM_CONV_VARIANT_FAST16) return "conv3x3_f16x2_t8x32";
     if (v >= 256) {
         // "<split-K variant>_k<parts>" and "<variant>_pair[_k<parts0>k<parts1>]": built on first use, kept for the process
         static std::mutex mu;

@@ -347,6 +347,10 @@ class Pipeline(abc.ABC):
             landmarks = host[: nl_all * 24].view(np.float64).reshape(nl_all, 3).copy()
             error = e3.mean_error(host[nl_all * 24: nl_all * 32].view(np.float64))
             r3.check()  # deferred renderer status (the .cpu() above already synchronised)
+        if getattr(p2, "precision", None) == "fast16" and not np.isfinite(landmarks).all():
+            # fp16 overflow somewhere in the network: every maximum downstream is non-finite.  Same scan again on bf16x3.
+            # (the global RNG stands behind this call's draws: the repeat draws again, as a second call would)
+            return p2.repeat_without_fp16(lambda: self.predict_mesh_device(mesh, transform_stack))
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error
         return landmarks, error

@@ -89,6 +89,8 @@ class HipPaulsenModel(Predictor2D):
                 self.get_lm_count(), self.in_channels))
             self._replicas.append(_Replica(rctx))
         self._fast_loaded = False
+        self._fast16_loaded = False
+        self.fast16_fallbacks = 0  # passes repeated with "fast" because an activation left fp16's range
         self.precision = "exact"
         self.set_precision(precision)
 
@@ -114,22 +116,29 @@ class HipPaulsenModel(Predictor2D):
 
     def set_precision(self, precision: str):
         """"exact" (default): every convolution in exact fp32 on the matrix cores - the path all parity claims are
-        about.  "fast" (opt-in): the big 3x3 layers multiply bf16x3-split operands (mvlm_amd/csrc/conv_fast.hip),
-        fp32-accurate but not bit-identical: argmax near-ties may flip, see bench.py's ``fast_mode`` figures."""
-        if precision not in ("exact", "fast"):
-            raise ValueError("precision must be 'exact' or 'fast'")
+        about.  Opt-in, fp32-accurate but not bit-identical (argmax near-ties may flip; bench.py reports both separately):
+        "fast" - the big 3x3 layers multiply bf16x3-split operands (6 cross products, mvlm_amd/csrc/conv_fast.hip);
+        "fast16" - f16x2-split operands (3 cross products: half the matrix work again).  fp16 overflows at 65520: a pass
+        whose activations get there returns non-finite maxima, and ``predict_device`` / the pipeline repeat it with "fast"."""
+        if precision not in ("exact", "fast", "fast16"):
+            raise ValueError("precision must be 'exact', 'fast' or 'fast16'")
+        holders = [self.ctx] + [r.ctx for r in self._replicas]
         if precision == "fast" and not self._fast_loaded:
             blob16, offsets = W.pack_fast_for_device(self._state_dict, self.get_lm_count(), self.in_channels, self._desc)
-            self.ctx.check(self.ctx.lib.mvlm_cnn_load_fast(
-                self.ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
-                offsets.ctypes.data_as(C.POINTER(C.c_int64)), offsets.shape[0]))
-            for r in self._replicas:
-                r.ctx.check(r.ctx.lib.mvlm_cnn_load_fast(
-                    r.ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
+            for ctx in holders:
+                ctx.check(ctx.lib.mvlm_cnn_load_fast(
+                    ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), offsets.shape[0]))
             self._fast_loaded = True
-        for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
-            ctx.check(ctx.lib.mvlm_cnn_set_precision(ctx.handle, 1 if precision == "fast" else 0))
+        if precision == "fast16" and not self._fast16_loaded:
+            blob16, offsets, unscale = W.pack_fast16_for_device(self._state_dict, self.get_lm_count(), self.in_channels, self._desc)
+            for ctx in holders:
+                ctx.check(ctx.lib.mvlm_cnn_load_fast16(
+                    ctx.handle, blob16.ctypes.data_as(C.POINTER(C.c_uint16)), blob16.size,
+                    offsets.ctypes.data_as(C.POINTER(C.c_int64)), _lib.as_ptr(unscale, C.c_float), offsets.shape[0]))
+            self._fast16_loaded = True
+        for ctx in holders:
+            ctx.check(ctx.lib.mvlm_cnn_set_precision(ctx.handle, {"exact": 0, "fast": 1, "fast16": 2}[precision]))
         self.precision = precision
 
     @abc.abstractmethod
@@ -319,7 +328,18 @@ class HipPaulsenModel(Predictor2D):
         valid = np.ones((n_views), dtype=bool)
         x = torch.from_numpy(np.ascontiguousarray(image_stack, dtype=np.float32)).to(torch.device("cuda", self.ctx.device))
         lms = self.predict_device(x).cpu().numpy()
+        if self.precision == "fast16" and not np.isfinite(lms[:, :, 2]).all():
+            lms = self.repeat_without_fp16(lambda: self.predict_device(x).cpu().numpy())
         return lms, valid
+
+    def repeat_without_fp16(self, run):
+        """An activation left fp16's range in a "fast16" pass (non-finite maxima): repeat ``run`` with the bf16x3 form, whose
+        exponent range is fp32's, and stay there for this predictor's remaining calls (the scan that overflows once will
+        again)."""
+        print('Warning: an activation exceeded the fp16 range of precision="fast16" - repeating the pass with precision="fast"')
+        self.fast16_fallbacks += 1
+        self.set_precision("fast")
+        return run()
 
 
 class _Replica:

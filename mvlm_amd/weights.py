@@ -219,3 +219,37 @@ def pack_fast_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channel
         cursor += n
     blob = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
     return blob, offsets
+
+
+def pack_fast16_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channels: int, desc: np.ndarray):
+    """The same layers for the second opt-in form, "fast16" (f16x2-split operands, conv_fast.hip): every weight scaled by
+    the layer's power of two and split into two fp16 terms by the library's packer (mvlm_pack_fast_weights16).
+    Returns (blob uint16[total], offsets int64[N_CONV_SLOTS] (-1: the layer stays exact), unscale float32[N_CONV_SLOTS])."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    slots = arch.conv_slots(n_landmarks, in_channels)
+    offsets = np.full(len(slots), -1, dtype=np.int64)
+    unscale = np.ones(len(slots), dtype=np.float32)
+    parts, cursor = [], 0
+    for s in slots:
+        cin_pad, cout_pad = _round_up(s.cin, 16), _round_up(s.cout, 64)
+        if not s.present or s.ksize != 3 or not 16 <= s.cin <= 256 or s.cout * 8 < cout_pad * 5:
+            continue
+        w = np.ascontiguousarray(sd[f"{s.name}.weight"], dtype=np.float32)
+        n = int(lib.mvlm_pack_fast_weights16(_lib.as_ptr(w, C.c_float), s.cout, s.cin, cout_pad, cin_pad, None, None))
+        if n == 0:
+            raise ValueError(f"mvlm_pack_fast_weights16 refused layer {s.name}")
+        buf = np.empty(n, dtype=np.uint16)
+        inv = C.c_float(1.0)
+        if int(lib.mvlm_pack_fast_weights16(_lib.as_ptr(w, C.c_float), s.cout, s.cin, cout_pad, cin_pad,
+                                            buf.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(inv))) != n:
+            raise ValueError(f"mvlm_pack_fast_weights16 failed on layer {s.name} (non-finite weights?)")
+        offsets[s.index] = cursor
+        unscale[s.index] = inv.value
+        parts.append(buf)
+        cursor += n
+    blob = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
+    return blob, offsets, unscale

@@ -139,8 +139,9 @@ def test_network_with_paired_residual_blocks(n_views):
         n = ctx.lib.mvlm_cnn_get_profile(ctx.handle, slot, var, fl, ms, cap)
     finally:
         ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0))
-    pairs = [var[i] for i in range(n) if var[i] & 0x1000]
-    assert n == 138 - len(pairs) and len(pairs) >= 24, (n, len(pairs))
+    convs = [var[i] for i in range(n) if slot[i] >= 0]           # (slot -1 = the pool kernel behind a block whose tiles cannot pool)
+    pairs = [v for v in convs if v & 0x1000]
+    assert len(convs) == 138 - len(pairs) and len(pairs) >= 24, (n, len(convs), len(pairs))
     assert all(b"_pair" in ctx.lib.mvlm_conv_variant_name(v) for v in pairs)
     pred.set_execution(graphs=True, pairing=1)
 
@@ -406,3 +407,136 @@ def test_end_to_end_matrix_over_seeds(dataset, mode, n_views, grid, seed):
     assert np.all(moved[~same] <= 1.2 * unit * diff_views.sum(axis=1)[~same])
     if same.all():
         assert abs(gerr - werr) <= 1e-6 * max(1.0, abs(werr))
+
+
+# ---- second opt-in precision: f16x2-split operands ("fast16") --------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,size,batch,opts", [
+    (256, 128, 64, 2, dict(pre=True, res=True)),       # a residual block's conv1
+    (256, 256, 32, 1, dict(bias=True, post=True)),     # conv5 / conv9 shape, two 128-channel tiles
+    (128, 64, 32, 3, dict(pre=True, res=True)),        # 64-channel tile (16 rows: three staging items)
+    (64, 64, 64, 1, dict(pre=True)),
+    (32, 64, 32, 2, dict(bias=True)),                  # two 16-channel chunks
+    (84, 256, 32, 2, dict(bias=True, res=True)),       # conv7: the last chunk partly empty
+    (256, 84, 64, 1, dict(bias=True)),                 # conv6 / conv10: 84 output channels in one 128-channel tile
+    (128, 128, 32, 1, dict(pre=True, scale=1e-3)),     # small weights: the per-layer power-of-two scale
+    (64, 128, 32, 1, dict(pre=True, scale=300.0, xscale=50.0)),   # large weights and activations, still inside fp16
+])
+def test_fast16_conv_matches_torch(cin, cout, size, batch, opts):
+    """mvlm_conv2d_fast16 (two fp16 terms per operand, 3 cross products, fp32 accumulation, weights scaled by the layer's
+    power of two) against torch float64: fp32-class accuracy (per product <= 3 x 2^-22), nothing like an fp16 convolution's 1e-3."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    rs = np.random.RandomState(cin + cout + size)
+    x = (rs.standard_normal((batch, cin, size, size)) * opts.get("xscale", 1.0)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9) * opts.get("scale", 1.0)).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32) if opts.get("bias") else None
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32)) if opts.get("pre") else None
+    post = (rs.uniform(0.5, 1.5, cout).astype(np.float32), (rs.standard_normal(cout) * 0.3).astype(np.float32)) if opts.get("post") else None
+    res = rs.standard_normal((batch, cout, size, size)).astype(np.float32) if opts.get("res") else None
+    xd = dev(x)
+    rd = dev(res) if res is not None else None
+    yd = torch.empty((batch, cout, size, size), dtype=torch.float32, device="cuda")
+    q = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+    ctx.check(ctx.lib.mvlm_conv2d_fast16(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, q(w), cout, q(bias),
+                                         q(pre[0]) if pre else None, q(pre[1]) if pre else None,
+                                         q(post[0]) if post else None, q(post[1]) if post else None,
+                                         C.c_void_p(rd.data_ptr()) if rd is not None else None, C.c_void_p(yd.data_ptr())))
+    t = torch.from_numpy(x).double()
+    if pre:
+        t = torch.relu(t * torch.from_numpy(pre[0]).double()[None, :, None, None] + torch.from_numpy(pre[1]).double()[None, :, None, None])
+    y = torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None if bias is None else torch.from_numpy(bias).double(), 1, 1)
+    if post:
+        y = torch.relu(y * torch.from_numpy(post[0]).double()[None, :, None, None] + torch.from_numpy(post[1]).double()[None, :, None, None])
+    if res is not None:
+        y = y + torch.from_numpy(res).double()
+    want = y.numpy()
+    err = np.abs(yd.cpu().numpy() - want).max()
+    assert err < 1e-5 * max(1.0, np.abs(want).max()), err
+
+
+@pytest.mark.parametrize("family", ["bu3dfe", "dtu3d"])
+def test_fast16_network_close_to_exact(family):
+    """precision="fast16" on the whole network: heatmaps within 1e-4 of the value range of the exact path's, argmax pixels
+    equal except near-ties; switching back restores the exact path bit for bit."""
+    from mvlm_amd.prediction import BU3DFEPredictor, DTU3DPredictor
+
+    imgs = dev(seeded_images(41, 4))
+    if family == "bu3dfe":
+        pred = BU3DFEPredictor(image_mode="RGB+depth", weights="synthetic:3", verbose=False)
+    else:
+        pred = DTU3DPredictor(image_mode="RGB", weights="synthetic:4", verbose=False)
+    exact_heat = pred.heatmaps_device(imgs).clone()
+    exact_max = pred.predict_device(imgs).clone()
+    pred.set_precision("fast16")
+    heat = pred.heatmaps_device(imgs)
+    fmax = pred.predict_device(imgs)
+    assert torch.isfinite(heat).all()
+    scale = exact_heat.abs().max().item()
+    dev_heat = (heat - exact_heat).abs().max().item()
+    assert 0 < dev_heat < 1e-4 * scale, (dev_heat, scale)
+    flips = (~torch.all(fmax[:, :, :2] == exact_max[:, :, :2], dim=2)).sum().item()
+    assert flips <= 0.03 * pred.get_lm_count() * 4, flips
+    pred.set_precision("exact")
+    assert torch.equal(pred.predict_device(imgs), exact_max)
+    assert pred.fast16_fallbacks == 0
+
+
+@pytest.mark.parametrize("name,mode,n_views", [("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)])
+def test_fast16_against_the_oracle(name, mode, n_views):
+    """precision="fast16" against the CPU ORACLE (never the default, never bench.py's value): the same render, at most
+    0.2 % of the argmax planes move (near-ties), every landmark whose views all picked the oracle's pixel within 1e-3."""
+    import contextlib
+    import io
+
+    from mvlm_amd import arch, pipeline, weights
+    from mvlm_amd.utils.synthetic import face_like_mesh
+    from oracle import pipeline as opipe
+
+    pipe = pipeline.create_pipeline(name, n_views=n_views, weights="synthetic:11", verbose=False, image_mode=mode, precision="fast16")
+    assert pipe.predictor_2d.precision == "fast16"
+    mesh = face_like_mesh(60, 128, 11)
+    np.random.seed(0)
+    poses = pipe.renderer_3d.generate_3d_transformations()
+    np.random.seed(1)
+    got, _ = pipe.predict_mesh_device(mesh, poses)
+    assert pipe.predictor_2d.precision == "fast16" and pipe.predictor_2d.fast16_fallbacks == 0
+    gmax = pipe.predictor_2d.predict_device(pipe.renderer_3d.render_device(mesh, poses)).cpu().numpy()
+    nl = pipe.get_lm_count()
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        want, _, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses,
+                                            weights.synthetic_state_dict(nl, arch.IMAGE_CHANNELS[mode], seed=11), arch.CHANNEL_SELECT[mode])
+    diff = ~np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)
+    assert diff.mean() <= 0.002, f"{int(diff.sum())} of {diff.size} argmax planes differ from the oracle"
+    same = ~diff.any(axis=1)
+    assert same.mean() > 0.95
+    assert np.abs(got[same] - want[same]).max() < 1e-3
+    scores = np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[~diff]
+    assert scores.max() < 1e-4 * max(1.0, np.abs(inter["maxima"][:, :, 2]).max())
+
+
+def test_fast16_overflow_falls_back_to_bf16x3(capsys):
+    """fp16 ends at 65504: with activations beyond that the f16x2 pass returns non-finite maxima - the predictor (numpy slot)
+    and the pipeline (fused path) notice, say so, repeat the pass on the bf16x3 form and stay there."""
+    from mvlm_amd import pipeline, weights
+    from mvlm_amd.utils.synthetic import face_like_mesh
+
+    sd = weights.synthetic_state_dict(73, 3, seed=5)
+    sd["conv1.weight"] = (sd["conv1.weight"] * 3.0e6).astype(np.float32)      # conv2.conv1's input leaves fp16's range
+    pipe = pipeline.create_pipeline("dtu3d", n_views=8, weights=sd, verbose=False, image_mode="RGB", precision="fast")
+    mesh = face_like_mesh(40, 64, 3)
+    poses = pipe.renderer_3d.generate_3d_transformations()
+    np.random.seed(1)
+    want, _ = pipe.predict_mesh_device(mesh, poses)
+    assert np.isfinite(want).all()
+    pipe.predictor_2d.set_precision("fast16")
+    np.random.seed(1)
+    got, _ = pipe.predict_mesh_device(mesh, poses)
+    assert pipe.predictor_2d.precision == "fast" and pipe.predictor_2d.fast16_fallbacks == 1
+    assert "fp16 range" in capsys.readouterr().out
+    np.testing.assert_array_equal(got, want)
+    pipe.predictor_2d.set_precision("fast16")
+    imgs = pipe.renderer_3d.render_device(mesh, poses).cpu().numpy()
+    lms, valid = pipe.predictor_2d.predict_landmarks_from_images(imgs)
+    assert np.isfinite(lms).all() and pipe.predictor_2d.precision == "fast" and pipe.predictor_2d.fast16_fallbacks == 2
