@@ -19,7 +19,7 @@ for v in 12 8; do
   python3 tools/per_level_table.py $OUT/bench_${v}views.stderr.txt > $OUT/per_level_${v}views.txt
   cat $OUT/per_level_${v}views.txt
 done
-MVLM_BENCH_PER_LAYER=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > $OUT/bench_96views.json 2> $OUT/bench_96views.stderr.txt || exit 1
+MVLM_BENCH_PER_LAYER=1 timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 > $OUT/bench_96views.json 2> $OUT/bench_96views.stderr.txt || exit 1
 python3 tools/per_level_table.py $OUT/bench_96views.stderr.txt > $OUT/per_level_96views.txt
 cat $OUT/per_level_96views.txt
 python3 -c "
@@ -27,4 +27,10 @@ import json
 for v in (12, 8, 96):
     r = json.load(open('$OUT/bench_%dviews.json' % v))
     print(v, 'views:', r['ms_per_step'], 'ms', r['value'], 'views/s  all_conv_frac', r['roofline']['all_conv_frac'], 'dominant', r['roofline']['frac'])
+"
+python3 -c "
+import json
+r = json.load(open('$OUT/bench_96views.json'))
+for k in ('fast_mode', 'fast16_mode'):
+    print(k, json.dumps(r.get(k)))
 "
