@@ -322,6 +322,11 @@ class Pipeline(abc.ABC):
             if self.verbose:
                 torch.cuda.synchronize()
 
+        # precision="fast16": an activation beyond fp16's range turns every maximum downstream non-finite (NaN scores survive no
+        # filter, so the landmarks themselves would come out as finite zeros): one flag, fetched after the step's own wait
+        fp16_guard = None
+        if getattr(p2, "precision", None) == "fast16":
+            fp16_guard = (~torch.isfinite(maxima[:, :, 2])).any()
         if plan is None:
             # the RANSAC draws for the expected survivor counts (~0.3 ms of numpy calls) are made now, while the GPU
             # works on the views; they travel through pinned memory on a copy stream of their own
@@ -347,7 +352,7 @@ class Pipeline(abc.ABC):
             landmarks = host[: nl_all * 24].view(np.float64).reshape(nl_all, 3).copy()
             error = e3.mean_error(host[nl_all * 24: nl_all * 32].view(np.float64))
             r3.check()  # deferred renderer status (the .cpu() above already synchronised)
-        if getattr(p2, "precision", None) == "fast16" and not np.isfinite(landmarks).all():
+        if fp16_guard is not None and (bool(fp16_guard.item()) or not np.isfinite(landmarks).all()):
             # fp16 overflow somewhere in the network: every maximum downstream is non-finite.  Same scan again on bf16x3.
             # (the global RNG stands behind this call's draws: the repeat draws again, as a second call would)
             return p2.repeat_without_fp16(lambda: self.predict_mesh_device(mesh, transform_stack))
@@ -360,6 +365,8 @@ class Pipeline(abc.ABC):
         p2, e3 = self.predictor_2d, self.estimator_3d
         if n_scans < 2 or not self._fusable() or not isinstance(p2, HipPaulsenModel):
             return False
+        if p2.precision == "fast16":
+            return False  # the fp16 range guard (and its fallback) works scan by scan
         if (self.shard_views and parallel.is_distributed()) or self.render_image_stack or self.visualize_rays:
             return False
         n = int(self.renderer_3d.n_views)

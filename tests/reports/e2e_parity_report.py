@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end parity report at a BASELINE size: GPU path vs CPU oracle on the same mesh, poses,
 weights and RNG seed.  Test infrastructure (imports oracle/); run on the GPU box.
-usage: tests/reports/e2e_parity_report.py [n_views] [grid] [dtu3d|bu3dfe] [exact|fast] [RGB+depth|RGB|...]
-(73 / 84 landmarks; "fast" = the opt-in bf16x3 precision against the SAME oracle)"""
+usage: tests/reports/e2e_parity_report.py [n_views] [grid] [dtu3d|bu3dfe] [exact|fast|fast16] [RGB+depth|RGB|...]
+(73 / 84 landmarks; "fast" / "fast16" = the opt-in bf16x3 / f16x2 precisions against the SAME oracle)"""
 import contextlib
 import io
 import sys

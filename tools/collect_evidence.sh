@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/README.md cites for one round, in one pass on the GPU box: usage tools/collect_evidence.sh r03
+# Everything profiles/README.md cites for one round, in one pass on the GPU box: usage tools/collect_evidence.sh r04
 # (results under gpurun_out/evidence_<tag>/ with the names they get in profiles/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/evidence_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -19,6 +19,11 @@ timeout -k 10 600 python3 tests/reports/parity_stats.py 8 > $OUT/${TAG}_parity_s
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe > $OUT/${TAG}_e2e_parity_96views.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe fast RGB+depth > $OUT/${TAG}_fast_vs_oracle_bu3dfe_rgbd_96views.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 64 224 dtu3d fast RGB > $OUT/${TAG}_fast_vs_oracle_dtu3d_rgb_64views.txt 2>&1 || exit 1
+timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe fast16 RGB+depth > $OUT/${TAG}_fast16_vs_oracle_bu3dfe_rgbd_96views.txt 2>&1 || exit 1
+timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 64 224 dtu3d fast16 RGB > $OUT/${TAG}_fast16_vs_oracle_dtu3d_rgb_64views.txt 2>&1 || exit 1
+echo "== moment selection (fused) beside simple" ; date
+timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_96views.json 2> /dev/null || exit 1
+timeout -k 10 300 python3 bench.py --config dtu3d-geomdepth-96 --views-total 12 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_12views.json 2> /dev/null || exit 1
 echo "== ingest segments, per-level tables" ; date
 timeout -k 10 300 python3 tools/ingest_segments.py > $OUT/${TAG}_ingest_segments.txt 2>&1 || exit 1
 for v in 8 12; do

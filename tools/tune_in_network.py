@@ -158,8 +158,8 @@ def write_header(rows):
         table[k] = r
     for k in sorted(table):
         r = table[k]
-        if r["kept"] == r["current"]:
-            continue  # the existing choice stands: the single-layer table / the rules keep answering for this key
+        # (every tuned key is listed, changed or not: the dispatcher takes the entry of the smallest tuned batch >= B, so a key
+        #  missing at one batch would inherit another batch's winner)
         kept_name = r["best_name"] if r["kept"] == r["best"] else r["current_name"]
         note = f"{kept_name} {r['best_us'] if r['kept'] == r['best'] else r['current_us']} us"
         if r["kept"] != r["current"]:
