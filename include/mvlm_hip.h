@@ -161,8 +161,9 @@ int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int 
  * fp16 terms (22 significant bits), the three cross products xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16 with fp32
  * accumulation: 3/16 of the exact path's matrix time.  Per product 3-4 x the error of the bf16x3 form, still of the order of
  * an fp32 summation's own rounding.  The weights are scaled per layer by a power of two on the host (fp16's exponent is
- * narrow; the epilogue multiplies by the inverse, exactly); an activation with |x| >= 65520 becomes inf and turns the
- * pass's maxima non-finite - the Python layer then repeats the pass with the bf16x3 form.
+ * narrow; the epilogue multiplies by the inverse, exactly); an activation with |x| >= 65504 has no fp16 form: the kernel
+ * raises a flag, the pass's maxima scores (mvlm_cnn_maxima) / the first value of every heatmap plane (mvlm_cnn_heatmaps)
+ * come back as NaN, and the Python layer repeats the pass with the bf16x3 form.
  *   mvlm_pack_fast_weights16: like mvlm_pack_fast_weights with two splits per operand; *unscale = the inverse scale.
  *   mvlm_cnn_load_fast16: after mvlm_cnn_load; slot_unscale[n_slots] = the inverse scale per conv slot.
  *   mvlm_conv2d_fast16: test hook like mvlm_conv2d_fast. */

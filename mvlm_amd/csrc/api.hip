@@ -51,6 +51,7 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
     if (ctx->cnn.blob) hipFree(ctx->cnn.blob);
     if (ctx->cnn.fast_blob) hipFree(ctx->cnn.fast_blob);
     if (ctx->cnn.fast16_blob) hipFree(ctx->cnn.fast16_blob);
+    if (ctx->cnn.fast16_flag) hipFree(ctx->cnn.fast16_flag);
     for (int i = 0; i < 2; ++i) {
         if (ctx->kparts_ws[i]) hipFree(ctx->kparts_ws[i]);
         if (ctx->kparts_cnt[i]) hipFree(ctx->kparts_cnt[i]);

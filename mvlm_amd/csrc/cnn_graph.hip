@@ -502,6 +502,9 @@ struct Exec {
     int forward(const float* images, const int* sel4, float* maxima, int view0, int n_total, float* heat) {
         const int NL = st.n_landmarks, C = st.in_channels;
         const int SLOT_CONV5 = 1 + 4 * 43;
+        if (st.fast == 2 && !dry) {  // f16x2 precision: the range flag of this pass starts clear (a memset node of the launch graph)
+            if (hipMemsetAsync(st.fast16_flag, 0, sizeof(unsigned), ctx->cur_stream()) != hipSuccess) return rc = ctx->fail("cnn: hipMemsetAsync failed");
+        }
         Tensor x0 = alloc(C, 256);
         if (!dry && mvlm_launch_pack_input(ctx, images, B, sel4, C, x0.p)) return 1;
         Tensor a0 = alloc(64, 256);
@@ -647,6 +650,7 @@ struct Exec {
             }
         }
         release(x10);
+        if (st.fast == 2 && !dry && !rc && mvlm_launch_fp16_poison(ctx, st.fast16_flag, heat ? nullptr : maxima, B, view0, n_total, NL, heat)) rc = 1;
         return rc;
     }
 };
@@ -974,6 +978,10 @@ extern "C" int mvlm_cnn_load_fast16(mvlm_ctx* ctx, const uint16_t* blob_host, si
     if (st.fast16_blob) {
         MVLM_CHECK_HIP(ctx, hipFree(st.fast16_blob));
         st.fast16_blob = nullptr;
+    }
+    if (!st.fast16_flag) {
+        MVLM_CHECK_HIP(ctx, hipMalloc(&st.fast16_flag, sizeof(unsigned)));
+        MVLM_CHECK_HIP(ctx, hipMemset(st.fast16_flag, 0, sizeof(unsigned)));
     }
     MVLM_CHECK_HIP(ctx, hipMalloc(&st.fast16_blob, n_u16 * sizeof(uint16_t)));
     MVLM_CHECK_HIP(ctx, hipMemcpy(st.fast16_blob, blob_host, n_u16 * sizeof(uint16_t), hipMemcpyHostToDevice));

@@ -113,6 +113,7 @@ struct ConvArgs {
     float* pool_out = nullptr;
     int pool_ctot = 0, pool_coff = 0;
     float fast_unscale = 1.f;  // f16x2 kernel only: inverse of the power-of-two scale its packed weights carry
+    unsigned* fast_ovf = nullptr;  // f16x2 kernel only: set to 1 when an activation lies outside fp16's range
     int pool_hint = 0;  // the caller wants the pooled tensor too (set for the variant choice, before pool_out is decided)
     // -DMVLM_CONV_TIMING builds only (tools/conv_phase_timing.py): u64[4] = summed cycles of wave 0 in
     // prologue / K loop / epilogue, number of workgroups
@@ -172,6 +173,7 @@ struct CnnState {
     unsigned short* fast16_blob = nullptr;   // the f16x2 form's packed weights, offsets and per-layer inverse scales
     std::vector<long long> fast16_off;
     std::vector<float> fast16_unscale;
+    unsigned* fast16_flag = nullptr;         // device word: an f16x2 launch of the current pass met |x| >= 65504
     std::vector<CnnGraphEntry> graphs;
     long graph_replays = 0, graph_captures = 0, eager_runs = 0, graph_failures = 0;
 };
@@ -312,5 +314,8 @@ int mvlm_launch_maxpool2(mvlm_ctx* ctx, const float* in, int planes, int H, int 
 int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int n_img, int view0, int n_views_total,
                            int nl, int parts, int size, float* maxima, int* best_idx = nullptr);
 // "moment" refinement of the fused argmax's peaks from conv10's output (misc.hip: moment_refine_kernel)
+// f16x2 precision: where *flag != 0 the pass's maxima scores (or the first heatmap value of every plane) become NaN
+int mvlm_launch_fp16_poison(mvlm_ctx* ctx, const unsigned* flag, float* maxima, int n_img, int view0, int n_views_total, int nl,
+                            float* heat);
 int mvlm_launch_moment_refine(mvlm_ctx* ctx, const float* x10, int n_img, int nl, int cin_pad, int cout_pad, const float* const w_par[4],
                               const float* bias, const int* best_idx, int view0, int n_views_total, float* maxima);

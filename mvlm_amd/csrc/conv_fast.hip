@@ -28,9 +28,9 @@
 // mantissas are exact in fp32, so the error per product is the operands' 2^-22 representation error plus the dropped
 // term: 3-4 x that of bf16x3, still below what the order of an fp32 summation over K = 2304 terms moves.  fp16 has a
 // narrow exponent: the weights are scaled by a power of two per layer on the host (largest |w| into [2^13, 2^14); the
-// epilogue multiplies by the inverse, exactly), activations go in as they are - |x| >= 65520 becomes +-inf and poisons
-// everything downstream with inf / NaN (the caller sees non-finite maxima and falls back, pipeline / predictor), small
-// activations lose nothing that matters: |x - (h + l)| <= max(2^-22 |x|, 2^-25).
+// epilogue multiplies by the inverse, exactly), activations go in as they are: |x| >= 65504 has no fp16 form - the kernel
+// raises the context's flag word, the executor turns that pass's maxima into NaN and the caller repeats the pass on bf16x3
+// (predictor / pipeline).  Small activations lose nothing that matters: |x - (h + l)| <= max(2^-22 |x|, 2^-25).
 // Layers it serves: 3x3, input channels a multiple of 16, output channels a multiple of 64, width a multiple of 32,
 // height of 8, plain NCHW output with optional bias / post-BN+ReLU / raw copy / one residual.  Everything else (and
 // every layer in the default "exact" precision) runs on conv_mfma_kernel.
@@ -179,6 +179,10 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     }
     const size_t w_block = size_t(6 * NS) * a.cout_pad * 8;  // u16 elements of one (chunk, tap row) block
 
+    // f16x2 only: has this thread seen an activation outside fp16's range?  The non-finite products it causes do NOT reliably
+    // reach the output (the next layer's ReLU is a v_max, which drops a NaN), so the kernel raises a flag word instead; the
+    // executor turns the pass's maxima into NaN when it is set (cnn_graph.hip) and the caller repeats the pass on bf16x3.
+    bool ovf = false;
     float xv[X_ITERS][8];      // the next chunk's activations, in flight / waiting for their split
     unsigned xq[NS][4];        // one item's eight channels as 16-bit pairs, per split
     u32x4 wv[W_ITERS];         // the next tap row's weights
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
             float v = xv[i][2 * jp + k];
             if (has_bn) v = fmaxf(fmaf(v, k ? sc.y : sc.x, k ? sh.y : sh.x), 0.f);
             v = inside && (!partial_cin || c + k < a.cin) ? v : 0.f;  // zero padding after the activation; channels past cin
+            if constexpr (NS == 2) ovf |= !(fabsf(v) < 65504.f);         // beyond fp16 (or NaN): the pass is flagged, see below
             if constexpr (NS == 3)
                 split3(v, &h[k], &m[k], &l[k]);
             else
@@ -435,6 +440,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
         epilogue(F_{}, T_{}, std::integral_constant<int, 3>{});
     else
         epilogue(F_{}, F_{}, std::integral_constant<int, 3>{});
+    if constexpr (NS == 2) {
+        if (ovf && a.fast_ovf) *a.fast_ovf = 1u;  // (every writer stores the same word)
+    }
 }
 
 template <int COUT_T, int TRI, bool GEN, int NS>
@@ -476,6 +484,7 @@ bool mvlm_conv_fast_ok(const ConvArgs& a) {
 int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& exact, const unsigned short* wq_dev, int splits, float unscale) {
     MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(exact) && wq_dev && (splits == 3 || splits == 2), "conv_fast: launch not eligible");
     ConvArgs a = exact;  // the split weights carry their own paddings
+    a.fast_ovf = splits == 2 ? ctx->cnn.fast16_flag : nullptr;
     a.cin_pad = mvlm_fast_cin_pad(a.cin);
     a.cout_pad = mvlm_fast_cout_pad(a.cout);
     a.fast_unscale = unscale;

@@ -297,6 +297,27 @@ int mvlm_launch_amax_final(mvlm_ctx* ctx, const float* val, const int* idx, int 
     return 0;
 }
 
+namespace {
+__global__ void fp16_poison_kernel(const unsigned* __restrict__ flag, float* __restrict__ maxima, int n_img, int view0, int n_views_total,
+                                   int nl, float* __restrict__ heat) {
+    if (*flag == 0u) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (image, landmark)
+    if (i >= n_img * nl) return;
+    const int b = i / nl, lm = i % nl;
+    if (maxima) maxima[(size_t(lm) * n_views_total + view0 + b) * 3 + 2] = __builtin_nanf("");
+    if (heat) heat[size_t(i) * MVLM_IMAGE_SIZE * MVLM_IMAGE_SIZE] = __builtin_nanf("");
+}
+}  // namespace
+
+int mvlm_launch_fp16_poison(mvlm_ctx* ctx, const unsigned* flag, float* maxima, int n_img, int view0, int n_views_total, int nl,
+                            float* heat) {
+    MVLM_REQUIRE(ctx, flag && (maxima || heat), "fp16 poison: null argument");
+    hipLaunchKernelGGL(fp16_poison_kernel, dim3((n_img * nl + 255) / 256), dim3(256), 0, ctx->cur_stream(), flag, maxima, n_img, view0,
+                       n_views_total, nl, heat);
+    MVLM_CHECK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 int mvlm_launch_moment_refine(mvlm_ctx* ctx, const float* x10, int n_img, int nl, int cin_pad, int cout_pad, const float* const w_par[4],
                               const float* bias, const int* best_idx, int view0, int n_views_total, float* maxima) {
     MVLM_REQUIRE(ctx, x10 && best_idx && maxima && w_par[0] && w_par[1] && w_par[2] && w_par[3], "moment: null argument");
