@@ -511,15 +511,27 @@ def test_fast16_against_the_oracle(name, mode, n_views):
     assert diff.mean() <= 0.002, f"{int(diff.sum())} of {diff.size} argmax planes differ from the oracle"
     scores = np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[~diff]
     assert scores.max() < 1e-4 * max(1.0, np.abs(inter["maxima"][:, :, 2]).max())
-    # The view filter keeps the views whose score exceeds the landmark's median (estimator3d.py:140-147): a rank decision.
-    # Scores that differ in the 6th digit can swap two views around the median, and with them a line of the bundle - the
-    # landmark then moves by much more than the scores did.  Compared: landmarks with the oracle's pixels AND its survivors.
+    # Downstream of the maxima the pass is the exact one: the oracle's estimator fed with THESE maxima (same RNG seed) gives
+    # the product's landmarks to 1e-8.
+    from oracle import estimator as oest
+    from oracle import surface
+
+    s_, e_ = oest.estimate_landmark_lines(256, gmax, poses)
+    np.random.seed(1)
+    fed, _ = oest.estimate_landmarks_from_lines(gmax, s_, e_)
+    np.testing.assert_allclose(got, surface.project_landmarks_to_surface(mesh.verts, mesh.tris, fed), rtol=0, atol=1e-8)
+    # Against the oracle's OWN maxima the comparison is rank-sensitive: the view filter keeps the views whose score exceeds
+    # the landmark's median (estimator3d.py:140-147), so scores that differ in the 6th digit can swap two views around the
+    # median (another line in the bundle), and a landmark whose median pair ties changes its survivor COUNT, which shifts the
+    # global RNG's draws of every landmark after it (estimator3d.py:105).  Compared: landmarks with the oracle's pixels and
+    # survivors, up to the first landmark whose survivor count differs.
     def survivors(m):
         v = m[:, :, 2]
         return v > np.quantile(v, 0.5, axis=1, keepdims=True)
-    same_filter = np.all(survivors(gmax) == survivors(inter["maxima"]), axis=1)
-    same = ~diff.any(axis=1) & same_filter
-    assert same_filter.mean() > 0.9 and same.mean() > 0.9, (same_filter.mean(), same.mean())
+    sg, so = survivors(gmax), survivors(inter["maxima"])
+    shifted = np.cumsum(sg.sum(axis=1) != so.sum(axis=1)) > 0          # the RNG stream is another one from here on
+    same = ~diff.any(axis=1) & np.all(sg == so, axis=1) & ~shifted
+    assert same.mean() > 0.5, (same.mean(), shifted.mean())
     assert np.abs(got[same] - want[same]).max() < 1e-3
 
 
