@@ -166,10 +166,13 @@ int mvlm_conv2d_fast(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int 
  * come back as NaN, and the Python layer repeats the pass with the bf16x3 form.
  *   mvlm_pack_fast_weights16: like mvlm_pack_fast_weights with two splits per operand; *unscale = the inverse scale.
  *   mvlm_cnn_load_fast16: after mvlm_cnn_load; slot_unscale[n_slots] = the inverse scale per conv slot.
+ *   mvlm_cnn_fast16_overflowed: *overflowed = 1 when the last mvlm_cnn_maxima / mvlm_cnn_heatmaps call on this context met
+ *     such an activation (waits for the context's stream).
  *   mvlm_conv2d_fast16: test hook like mvlm_conv2d_fast. */
 size_t mvlm_pack_fast_weights16(const float* w, int cout, int cin, int cout_pad, int cin_pad, uint16_t* out, float* unscale);
 int mvlm_cnn_load_fast16(mvlm_ctx* ctx, const uint16_t* blob_host, size_t n_u16, const int64_t* slot_offsets,
                          const float* slot_unscale, int n_slots);
+int mvlm_cnn_fast16_overflowed(mvlm_ctx* ctx, int* overflowed);
 int mvlm_conv2d_fast16(mvlm_ctx* ctx, const float* x_dev, int batch, int cin, int h, int w, const float* w_host, int cout,
                        const float* bias_host, const float* pre_scale_host, const float* pre_shift_host,
                        const float* post_scale_host, const float* post_shift_host, const float* r_dev, float* y_dev);

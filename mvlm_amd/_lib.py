@@ -58,6 +58,7 @@ SIGNATURES = {
     "mvlm_cnn_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_pack_fast_weights16": (C.c_size_t, [c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), c_float_p]),
     "mvlm_cnn_load_fast16": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16), C.c_size_t, C.POINTER(C.c_int64), c_float_p, C.c_int]),
+    "mvlm_cnn_fast16_overflowed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mvlm_conv2d_fast16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p,
                                      c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_void_p]),
     "mvlm_conv2d_fast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p,

@@ -502,9 +502,6 @@ struct Exec {
     int forward(const float* images, const int* sel4, float* maxima, int view0, int n_total, float* heat) {
         const int NL = st.n_landmarks, C = st.in_channels;
         const int SLOT_CONV5 = 1 + 4 * 43;
-        if (st.fast == 2 && !dry) {  // f16x2 precision: the range flag of this pass starts clear (a memset node of the launch graph)
-            if (hipMemsetAsync(st.fast16_flag, 0, sizeof(unsigned), ctx->cur_stream()) != hipSuccess) return rc = ctx->fail("cnn: hipMemsetAsync failed");
-        }
         Tensor x0 = alloc(C, 256);
         if (!dry && mvlm_launch_pack_input(ctx, images, B, sel4, C, x0.p)) return 1;
         Tensor a0 = alloc(64, 256);
@@ -778,6 +775,9 @@ int run_cnn(mvlm_ctx* ctx, const float* images, int n_views, const int32_t* chan
     }
     st.prof.clear();
     st.event_cursor = 0;
+    // f16x2 precision: the range flag of this call starts clear (all device batches of the call share it: an overflow in
+    // one batch poisons that batch's and the later batches' maxima, and mvlm_cnn_fast16_overflowed reports it afterwards)
+    if (st.fast == 2) MVLM_CHECK_HIP(ctx, hipMemsetAsync(st.fast16_flag, 0, sizeof(unsigned), ctx->stream));
     const size_t img_elems = size_t(MVLM_IMAGE_SIZE) * MVLM_IMAGE_SIZE;
     for (int v0 = 0; v0 < n_views; v0 += batch) {
         const int nb = (n_views - v0) < batch ? (n_views - v0) : batch;
@@ -987,6 +987,20 @@ extern "C" int mvlm_cnn_load_fast16(mvlm_ctx* ctx, const uint16_t* blob_host, si
     MVLM_CHECK_HIP(ctx, hipMemcpy(st.fast16_blob, blob_host, n_u16 * sizeof(uint16_t), hipMemcpyHostToDevice));
     st.fast16_off.assign(slot_offsets, slot_offsets + n_slots);
     st.fast16_unscale.assign(slot_unscale, slot_unscale + n_slots);
+    return 0;
+}
+
+// did an f16x2 launch of the last mvlm_cnn_maxima / mvlm_cnn_heatmaps call meet an activation outside fp16's range?  Waits for
+// the context's stream (callers ask after their own wait for the results, when that costs nothing) and copies one word back.
+extern "C" int mvlm_cnn_fast16_overflowed(mvlm_ctx* ctx, int* overflowed) {
+    MVLM_ENTER(ctx);
+    MVLM_REQUIRE(ctx, overflowed, "cnn_fast16_overflowed: null output");
+    *overflowed = 0;
+    if (!ctx->cnn.fast16_flag) return 0;
+    unsigned v = 0;
+    MVLM_CHECK_HIP(ctx, hipMemcpyAsync(&v, ctx->cnn.fast16_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    MVLM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *overflowed = v != 0u;
     return 0;
 }
 

@@ -322,11 +322,6 @@ class Pipeline(abc.ABC):
             if self.verbose:
                 torch.cuda.synchronize()
 
-        # precision="fast16": an activation beyond fp16's range turns every maximum downstream non-finite (NaN scores survive no
-        # filter, so the landmarks themselves would come out as finite zeros): one flag, fetched after the step's own wait
-        fp16_guard = None
-        if getattr(p2, "precision", None) == "fast16":
-            fp16_guard = (~torch.isfinite(maxima[:, :, 2])).any()
         if plan is None:
             # the RANSAC draws for the expected survivor counts (~0.3 ms of numpy calls) are made now, while the GPU
             # works on the views; they travel through pinned memory on a copy stream of their own
@@ -352,8 +347,10 @@ class Pipeline(abc.ABC):
             landmarks = host[: nl_all * 24].view(np.float64).reshape(nl_all, 3).copy()
             error = e3.mean_error(host[nl_all * 24: nl_all * 32].view(np.float64))
             r3.check()  # deferred renderer status (the .cpu() above already synchronised)
-        if fp16_guard is not None and (bool(fp16_guard.item()) or not np.isfinite(landmarks).all()):
-            # fp16 overflow somewhere in the network: every maximum downstream is non-finite.  Same scan again on bf16x3.
+        if getattr(p2, "precision", None) == "fast16" and p2.fast16_overflowed():
+            # an activation beyond fp16's range somewhere in the network (the kernel raised the context's flag; the maxima of
+            # the pass carry NaN scores, which survive no filter - the landmarks above are finite nonsense).  Same scan again
+            # on bf16x3; asked here, after the step's own wait for its results, the question costs one 4-byte copy.
             # (the global RNG stands behind this call's draws: the repeat draws again, as a second call would)
             return p2.repeat_without_fp16(lambda: self.predict_mesh_device(mesh, transform_stack))
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")

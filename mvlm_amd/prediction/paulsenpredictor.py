@@ -328,9 +328,19 @@ class HipPaulsenModel(Predictor2D):
         valid = np.ones((n_views), dtype=bool)
         x = torch.from_numpy(np.ascontiguousarray(image_stack, dtype=np.float32)).to(torch.device("cuda", self.ctx.device))
         lms = self.predict_device(x).cpu().numpy()
-        if self.precision == "fast16" and not np.isfinite(lms[:, :, 2]).all():
+        if self.precision == "fast16" and self.fast16_overflowed():
             lms = self.repeat_without_fp16(lambda: self.predict_device(x).cpu().numpy())
         return lms, valid
+
+    def fast16_overflowed(self) -> bool:
+        """Did the last "fast16" pass meet an activation outside fp16's range (on any replica)?  Waits for the passes; ask
+        after the results have been fetched."""
+        hit = False
+        for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
+            v = C.c_int(0)
+            ctx.check(ctx.lib.mvlm_cnn_fast16_overflowed(ctx.handle, C.byref(v)))
+            hit = hit or bool(v.value)
+        return hit
 
     def repeat_without_fp16(self, run):
         """An activation left fp16's range in a "fast16" pass (non-finite maxima): repeat ``run`` with the bf16x3 form, whose

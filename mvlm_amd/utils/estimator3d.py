@@ -132,8 +132,13 @@ class HipEstimator3D:
             key = (n_landmarks, int(slot))
             bufs = self._draw_bufs.get(key)
             if bufs is None:
-                bufs = self._draw_bufs[key] = (torch.empty((n_landmarks, 8), dtype=torch.int32).pin_memory(),
-                                               torch.empty((n_landmarks, 8), dtype=torch.int32, device=dev),
+                # the device table is written by the UPLOAD stream: it is allocated under that stream, i.e. from that stream's
+                # pool of torch's caching allocator - a block the compute stream has just freed (and whose last kernel may
+                # still be queued there) can then never be handed out for it (round 4: temporaries of a torch op issued
+                # right before the first plan of a new landmark count were, and the late kernel overwrote the draws)
+                with torch.cuda.stream(self._upload_stream):
+                    table = torch.empty((n_landmarks, 8), dtype=torch.int32, device=dev)
+                bufs = self._draw_bufs[key] = (torch.empty((n_landmarks, 8), dtype=torch.int32).pin_memory(), table,
                                                torch.cuda.Event(), torch.cuda.Event())
             pinned, dev_buf, event, consumed = bufs
             event.synchronize()  # the previous upload out of this staging buffer has completed
