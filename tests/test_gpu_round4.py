@@ -559,3 +559,30 @@ def test_fast16_overflow_falls_back_to_bf16x3(capsys):
     imgs = pipe.renderer_3d.render_device(mesh, poses).cpu().numpy()
     lms, valid = pipe.predictor_2d.predict_landmarks_from_images(imgs)
     assert np.isfinite(lms).all() and pipe.predictor_2d.precision == "fast" and pipe.predictor_2d.fast16_fallbacks == 2
+
+
+def test_draw_table_of_a_new_landmark_count_is_not_overwritten():
+    """Regression (round 4): the RANSAC draw table lives on the device and is written by the estimator's UPLOAD stream.  It used
+    to be allocated from the compute stream's pool of torch's caching allocator; a torch op issued right before the first plan
+    of a NEW landmark count could leave a freed temporary there whose kernel was still queued, the table took that block, and
+    the late kernel overwrote the draws (the fused path then disagreed with the slot estimator on the same maxima).  Two
+    pipelines with different landmark counts in one process, torch temporaries in flight before the second one's first plan."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.synthetic import face_like_mesh
+
+    mesh = face_like_mesh(60, 128, 11)
+    for name, mode, nv in (("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)):
+        pipe = pipeline.create_pipeline(name, n_views=nv, weights="synthetic:11", verbose=False, image_mode=mode)
+        np.random.seed(0)
+        poses = pipe.renderer_3d.generate_3d_transformations()
+        junk = [torch.rand((84, 12, 3), device="cuda") for _ in range(8)]
+        _ = [(~torch.isfinite(j[:, :, 2])).any() for j in junk]      # temporaries allocated and freed on the compute stream
+        del junk
+        np.random.seed(1)
+        got, _ = pipe.predict_mesh_device(mesh, poses)
+        gmax = pipe._buffers["maxima"].cpu().numpy()
+        e3 = pipe.estimator_3d
+        s2, e2 = e3.estimate_landmark_lines(np.zeros((nv, 256, 256, 4), np.float32), gmax, poses)
+        np.random.seed(1)
+        out2, _ = e3.estimate_landmarks_from_lines(gmax, s2, e2)
+        np.testing.assert_array_equal(got, e3.project_landmarks_to_surface(mesh, out2))
