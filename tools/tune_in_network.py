@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--batches", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,20,24,32,48,64,96,128")
     ap.add_argument("--nets", default="dtu3d:geometry+depth,bu3dfe:RGB+depth")
     ap.add_argument("--write-header", action="store_true")
+    ap.add_argument("--merge", action="store_true", help="keep the entries of the existing header that this run does not re-measure")
     ap.add_argument("--out", default=str(REPO / "gpurun_out" / "conv_net_tune.json"))
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--min-gain", type=float, default=0.02)
@@ -139,10 +140,10 @@ def main():
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(rows, indent=0))
     if args.write_header:
-        write_header(rows)
+        write_header(rows, args.merge)
 
 
-def write_header(rows):
+def write_header(rows, merge=False):
     lines = ["// GENERATED by tools/tune_in_network.py --write-header on an MI355X: kernel variant per (layer shape, kind, device batch),",
              "// every candidate timed INSIDE a forward pass of the landmark network on real activations (HIP events per launch).",
              "// {ksize, cin_pad, cout_pad, size, kind, batch, variant}; kind 0 plain / residual-block layer, 1 scatter into the skip tensor,",
@@ -150,21 +151,25 @@ def write_header(rows):
              "#ifndef MVLM_CONV_TUNED_NET_H", "#define MVLM_CONV_TUNED_NET_H",
              "struct ConvTunedNet { short ksize, cin_pad, cout_pad, size, kind, batch, variant; };",
              "static const ConvTunedNet MVLM_CONV_TUNED_NET[] = {"]
+    import re
+
     table = {}
+    if merge and HEADER.exists():
+        for m in re.finditer(r"^    \{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (-?\d+)\},\s*// (.*)$", HEADER.read_text(), re.M):
+            table[tuple(int(m[i]) for i in range(1, 7))] = (int(m[7]), m[8])
     for r in rows:
         if r.get("summary"):
             continue
-        k = tuple(r["key"]) + (r["batch"],)
-        table[k] = r
-    for k in sorted(table):
-        r = table[k]
         # (every tuned key is listed, changed or not: the dispatcher takes the entry of the smallest tuned batch >= B, so a key
         #  missing at one batch would inherit another batch's winner)
         kept_name = r["best_name"] if r["kept"] == r["best"] else r["current_name"]
         note = f"{kept_name} {r['best_us'] if r['kept'] == r['best'] else r['current_us']} us"
         if r["kept"] != r["current"]:
             note += f" (was {r['current_name']} {r['current_us']} us)"
-        lines.append(f"    {{{k[0]}, {k[1]}, {k[2]}, {k[3]}, {k[4]}, {k[5]}, {r['kept']}}},  // {note}")
+        table[tuple(r["key"]) + (r["batch"],)] = (r["kept"], note + f" [{r['net']}]")
+    for k in sorted(table):
+        v, note = table[k]
+        lines.append(f"    {{{k[0]}, {k[1]}, {k[2]}, {k[3]}, {k[4]}, {k[5]}, {v}}},  // {note}")
     n = sum(1 for ln in lines if ln.startswith("    {"))
     if n == 0:
         lines.append("    {0, 0, 0, 0, 0, 0, -1},")
