@@ -169,10 +169,15 @@ def all_gather_views(local, n_total: int):
 
     rank, world = rank_world()
     nl = local.shape[0]
-    n_max = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
-    # fixed-size slots: [n_max, NL, 3] per rank, padded; one collective
-    send = torch.zeros((n_max, nl, 3), dtype=local.dtype, device=local.device)
-    send[: local.shape[1]] = local.permute(1, 0, 2)
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    n_max = max(sizes)
+    even = min(sizes) == n_max          # every rank holds the same number of views: no padding, no per-rank slicing
+    # fixed-size slots: [n_max, NL, 3] per rank (padded when the shards are uneven); one collective
+    if even:
+        send = local.permute(1, 0, 2).contiguous()
+    else:
+        send = torch.zeros((n_max, nl, 3), dtype=local.dtype, device=local.device)
+        send[: local.shape[1]] = local.permute(1, 0, 2)
     recv = torch.empty((world * n_max, nl, 3), dtype=local.dtype, device=local.device)
     if dist.get_backend() == "gloo" and send.is_cuda:
         # rehearsal on one GPU (several ranks share a device, which RCCL refuses): stage through the host
@@ -182,9 +187,10 @@ def all_gather_views(local, n_total: int):
             recv.copy_(r_cpu)
     else:
         with _Timed("all_gather", send.is_cuda):
-            dist.all_gather_into_tensor(recv, send.contiguous())
+            dist.all_gather_into_tensor(recv, send)
+    if even:
+        return recv.permute(1, 0, 2).contiguous()
     parts = []
     for r in range(world):
-        s, e = shard_range(n_total, r, world)
-        parts.append(recv[r * n_max: r * n_max + (e - s)])
+        parts.append(recv[r * n_max: r * n_max + sizes[r]])
     return torch.cat(parts, 0).permute(1, 0, 2).contiguous()
