@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Report how far the HIP network is from the CPU oracle (torch fp32, oneDNN): heatmap
 deviation and argmax differences.  Test infrastructure (imports oracle/); run on the GPU box.
-usage: tests/reports/parity_stats.py [n_views]"""
+usage: tests/reports/parity_stats.py [n_views]   (the exact path, then the two opt-in precisions against the same oracle)"""
 import sys
 from pathlib import Path
 
@@ -20,15 +20,17 @@ for nl, mode, c, seed in ((73, "RGB", 3, 1), (84, "RGB+depth", 4, 2)):
     imgs = seeded_images(500 + seed, n)
     cls = BU3DFEPredictor if nl == 84 else DTU3DPredictor
     pred = cls(image_mode=mode, weights=f"synthetic:{seed}", verbose=False)
-    heat = pred.heatmaps_device(torch.from_numpy(imgs).cuda()).cpu().numpy()
     sd = weights.synthetic_state_dict(nl, c, seed=seed)
     lms, _, oheat = ocnn.predict_landmarks_from_images(sd, imgs, arch.CHANNEL_SELECT[mode], return_heatmaps=True)
     oheat = oheat.numpy()
-    mine = ocnn.maxima_fast(torch.from_numpy(heat))
     scale = np.abs(oheat).max()
-    d = np.abs(heat - oheat)
-    flips = int((~np.all(mine[:, :, :2] == lms[:, :, :2], axis=2)).sum())
     top2 = np.sort(oheat.reshape(n, nl, -1), axis=2)[:, :, -2:]
     gap = (top2[..., 1] - top2[..., 0]) / scale
-    print(f"{nl}_{mode}: max|d|/max|h| = {d.max() / scale:.3e}  mean|d|/max|h| = {d.mean() / scale:.3e}  "
-          f"argmax differences {flips}/{n * nl}  (oracle top-2 gap: min {gap.min():.2e}, median {np.median(gap):.2e})")
+    for precision in ("exact", "fast", "fast16"):
+        pred.set_precision(precision)
+        heat = pred.heatmaps_device(torch.from_numpy(imgs).cuda()).cpu().numpy()
+        mine = ocnn.maxima_fast(torch.from_numpy(heat))
+        d = np.abs(heat - oheat)
+        flips = int((~np.all(mine[:, :, :2] == lms[:, :, :2], axis=2)).sum())
+        print(f"{nl}_{mode} {precision:6s}: max|d|/max|h| = {d.max() / scale:.3e}  mean|d|/max|h| = {d.mean() / scale:.3e}  "
+              f"argmax differences {flips}/{n * nl}  (oracle top-2 gap: min {gap.min():.2e}, median {np.median(gap):.2e})")
