@@ -26,6 +26,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // COUT_T x (TW x TRI x NIMG) output tile, KS x KS taps, CK input channels per LDS stage
+// (PIX_T == 64, round 4: TWO 32-pixel columns per workgroup on one staged weight slice - a launch of the small levels is
+//  bound by staging 36 bytes of weights per input channel and output row for 32 pixels of matrix work; a second column
+//  halves that traffic per MFMA.  These tiles have no K-parts form and no fused argmax.)
 // SPLITK: the four waves of a workgroup share ONE 32x32 output tile and each sums a quarter of
 // every K-chunk's channels (latency-bound tiny feature maps: 4x more workgroups, 4x shorter serial
 // K loop per wave); the partial sums are added in wave order through LDS, i.e. deterministically.
@@ -53,7 +56,7 @@ struct Cfg {
     static constexpr bool TAIL16 = COUT_T % 32 == 16 || TAIL4;
     // the fused argmax serves the last layer only (73 / 84 landmarks -> 80 / 96-row tiles of 8x32 pixels)
     static constexpr bool HAS_AMAX = NIMG == 1 && TW == 32 && TRI == 8 && KS != 1 && (COUT_T == 80 || COUT_T == 96 || (COUT_T == 84 && KS == 2));
-    static constexpr int NT = SPLITK ? 1 : PIX_T / 4 / 32;
+    static constexpr int NT = SPLITK ? PIX_T / 32 : PIX_T / 4 / 32;  // split-K: every wave multiplies all (one or two) 32-pixel columns
     static constexpr int NT16 = TAIL16 ? 2 * NT : 1;  // 16-pixel column groups of a wave
     static constexpr int KSTEPS = TAPS * CKW / 2;
     static constexpr int X_ITERS = (XT + 255) / 256;
@@ -62,14 +65,14 @@ struct Cfg {
     static constexpr size_t LDS_BYTES = size_t(2 * STAGE + 2 * BN_MAXC) * 4;
     // accumulators + staged tile + operands: above ~200 registers the kernel is told it owns
     // the whole SIMD register file (one wave per SIMD) instead of spilling for occupancy
-    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? 1 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0) + (TAIL4 ? 4 : 0);
+    static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? PIX_T / 32 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0) + (TAIL4 ? 4 : 0);
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
     // variants that also exist as a two-problem launch (conv_pair_kernel): the tiles of the residual blocks' 3x3 convolutions
-    static constexpr bool PAIRABLE = KS == 3 && COUT_T % 32 == 0 && COUT_T != 96;
-    static_assert(SPLITK ? (PIX_T == 32 && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
-                  "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one column for split-K)");
+    static constexpr bool PAIRABLE = KS == 3 && COUT_T % 32 == 0 && COUT_T != 96 && !(SPLITK && PIX_T != 32);
+    static_assert(SPLITK ? ((PIX_T == 32 || PIX_T == 64) && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
+                  "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one or two columns for split-K)");
     static_assert(!TAIL4 || PIX_T == 256, "the 4-row strip gives every lane of a wave one pixel: 64 pixels per wave");
     static_assert(COUT_T % 32 == 0 || (TAIL16 && !SPLITK && CK == 4 && TW == 32 && NIMG == 1),
                   "cout tile must be a multiple of the 32-row MFMA tile (+ one 16-row strip on the 32-pixel-row tiles)");
@@ -100,6 +103,10 @@ struct SplitKTail {
     unsigned b = 0, pix = 0;
     int y = 0, x = 0;
     float res[4] = {0.f, 0.f, 0.f, 0.f};
+};
+template <int N>
+struct SplitKTails {
+    SplitKTail t[N];
 };
 
 // Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
@@ -424,30 +431,35 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     // accumulator registers 4w..4w+3 = the channels co0 + 8w + 4 half + (0..3) and finishes them alone, so the four
     // waves' epilogues run side by side.  Its residual values are requested HERE, before the K loop: the epilogue of
     // these latency-bound launches then adds and stores without a memory round trip of its own.
-    SplitKTail sk;
+    SplitKTails<C::SPLITK ? C::NT : 1> sks;
     if constexpr (C::SPLITK) {
         if (a.kparts <= 1) {
-            const int rr = l31 / C::TW;
-            const int b = b0 + rr / C::TRI;
-            const int y = y0 + rr % C::TRI, x = x0 + l31 % C::TW;
-            sk.ok = C::NIMG == 1 ? true : (b < a.B);
-            sk.b = sk.ok ? unsigned(b) : 0u;
-            sk.pix = unsigned(y * a.W + x);
-            sk.y = y;
-            sk.x = x;
-            const unsigned HWo = unsigned(a.H) * unsigned(a.W);
-            const int cl = co0 + 8 * wave + 4 * half;  // this lane's first channel
-            if (a.res1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int cs = (cl + j < a.cout) ? cl + j : 0;  // padded channel rows read inside the tensor
-                    sk.res[j] = a.res1[(size_t(sk.b) * a.res1_ctot + a.res1_coff + cs) * HWo + sk.pix];
-                }
-                if (a.res2) {
+            for (int n = 0; n < C::NT; ++n) {
+                SplitKTail& sk = sks.t[n];
+                const int p = n * 32 + l31;
+                const int rr = p / C::TW;
+                const int b = b0 + rr / C::TRI;
+                const int y = y0 + rr % C::TRI, x = x0 + p % C::TW;
+                sk.ok = C::NIMG == 1 ? true : (b < a.B);
+                sk.b = sk.ok ? unsigned(b) : 0u;
+                sk.pix = unsigned(y * a.W + x);
+                sk.y = y;
+                sk.x = x;
+                const unsigned HWo = unsigned(a.H) * unsigned(a.W);
+                const int cl = co0 + 8 * wave + 4 * half;  // this lane's first channel
+                if (a.res1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int cs = (cl + j < a.cout) ? cl + j : 0;
-                        sk.res[j] += a.res2[(size_t(sk.b) * a.res2_ctot + a.res2_coff + cs) * HWo + sk.pix];
+                        const int cs = (cl + j < a.cout) ? cl + j : 0;  // padded channel rows read inside the tensor
+                        sk.res[j] = a.res1[(size_t(sk.b) * a.res1_ctot + a.res1_coff + cs) * HWo + sk.pix];
+                    }
+                    if (a.res2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int cs = (cl + j < a.cout) ? cl + j : 0;
+                            sk.res[j] += a.res2[(size_t(sk.b) * a.res2_ctot + a.res2_coff + cs) * HWo + sk.pix];
+                        }
                     }
                 }
             }
@@ -502,22 +514,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     if constexpr (C::SPLITK && !AMAX) {
         if (a.kparts <= 1) {
             // every wave leaves its partial tile in LDS, then wave w adds registers 4w..4w+3 of the four partials in wave
-            // order ((w0 + w1) + w2) + w3 - the order of the single-wave reduction below, bit for bit - and finishes them
+            // order ((w0 + w1) + w2) + w3 - the order of the single-wave reduction below, bit for bit - and finishes them;
+            // a two-column tile does that column by column through the same buffer
             static_assert(!C::SPLITK || 2 * C::STAGE >= 4 * 16 * 64, "the four partial tiles must fit the two stages");
-            __syncthreads();  // every wave is done reading the stages: reuse them as the exchange buffer
             float* const red = smem;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
-            __syncthreads();
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = red[(0 * 16 + 4 * wave + j) * 64 + lane];
-                t += red[(1 * 16 + 4 * wave + j) * 64 + lane];
-                t += red[(2 * 16 + 4 * wave + j) * 64 + lane];
-                t += red[(3 * 16 + 4 * wave + j) * 64 + lane];
-                v[j] = t;
-            }
             const unsigned HWo = unsigned(a.H) * unsigned(a.W);
             const int cl = co0 + 8 * wave + 4 * half;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
@@ -526,52 +526,69 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
                 ps4 = *reinterpret_cast<const f32x4*>(a.post_scale + cl);
                 pt4 = *reinterpret_cast<const f32x4*>(a.post_shift + cl);
             }
+            static_for<0, C::NT>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                const SplitKTail& sk = sks.t[n];
+                __syncthreads();  // every wave is done reading the stages (or the previous column's partials): reuse them as the exchange buffer
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (a.bias) v[j] += bias4[j];
-                if (a.post_scale) v[j] = fmaxf(fmaf(v[j], ps4[j], pt4[j]), 0.f);
-            }
-            if (a.out_raw) {
+                for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][n][r];
+                __syncthreads();
+                float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (sk.ok && cl + j < a.cout) a.out_raw[(size_t(sk.b) * a.raw_ctot + a.raw_coff + cl + j) * HWo + sk.pix] = v[j];
-            }
-            if (a.res1) {
+                for (int j = 0; j < 4; ++j) {
+                    float t = red[(0 * 16 + 4 * wave + j) * 64 + lane];
+                    t += red[(1 * 16 + 4 * wave + j) * 64 + lane];
+                    t += red[(2 * 16 + 4 * wave + j) * 64 + lane];
+                    t += red[(3 * 16 + 4 * wave + j) * 64 + lane];
+                    v[j] = t;
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += sk.res[j];
-            }
-            if (a.out) {
-                if (!a.up_out) {
+                for (int j = 0; j < 4; ++j) {
+                    if (a.bias) v[j] += bias4[j];
+                    if (a.post_scale) v[j] = fmaxf(fmaf(v[j], ps4[j], pt4[j]), 0.f);
+                }
+                if (a.out_raw) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (sk.ok && cl + j < a.cout) a.out[(size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * HWo + sk.pix] = v[j];
-                } else if (a.up_out == 2) {
-                    const unsigned o2 = unsigned(2 * sk.y + a.sub_y) * unsigned(2 * a.W) + unsigned(2 * sk.x + a.sub_x);
+                        if (sk.ok && cl + j < a.cout) a.out_raw[(size_t(sk.b) * a.raw_ctot + a.raw_coff + cl + j) * HWo + sk.pix] = v[j];
+                }
+                if (a.res1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (sk.ok && cl + j < a.cout) a.out[(size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * (4u * HWo) + o2] = v[j];
-                } else {
-                    // hourglass up-path: the value goes to its 2x2 block of the skip tensor, added in place (:334-359)
-                    const unsigned W2 = 2u * unsigned(a.W);
-                    const unsigned o2 = unsigned(2 * sk.y) * W2 + unsigned(2 * sk.x);
-                    float2 s0[4], s1[4];
+                    for (int j = 0; j < 4; ++j) v[j] += sk.res[j];
+                }
+                if (a.out) {
+                    if (!a.up_out) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int cs = (cl + j < a.cout) ? cl + j : 0;
-                        const float* const ps = a.skip + (size_t(sk.b) * a.skip_ctot + a.skip_coff + cs) * (4u * HWo) + o2;
-                        s0[j] = *reinterpret_cast<const float2*>(ps);
-                        s1[j] = *reinterpret_cast<const float2*>(ps + W2);
-                    }
+                        for (int j = 0; j < 4; ++j)
+                            if (sk.ok && cl + j < a.cout) a.out[(size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * HWo + sk.pix] = v[j];
+                    } else if (a.up_out == 2) {
+                        const unsigned o2 = unsigned(2 * sk.y + a.sub_y) * unsigned(2 * a.W) + unsigned(2 * sk.x + a.sub_x);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (sk.ok && cl + j < a.cout) {
-                            float* const po = a.out + (size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * (4u * HWo) + o2;
-                            *reinterpret_cast<float2*>(po) = make_float2(v[j] + s0[j].x, v[j] + s0[j].y);
-                            *reinterpret_cast<float2*>(po + W2) = make_float2(v[j] + s1[j].x, v[j] + s1[j].y);
+                        for (int j = 0; j < 4; ++j)
+                            if (sk.ok && cl + j < a.cout) a.out[(size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * (4u * HWo) + o2] = v[j];
+                    } else {
+                        // hourglass up-path: the value goes to its 2x2 block of the skip tensor, added in place (:334-359)
+                        const unsigned W2 = 2u * unsigned(a.W);
+                        const unsigned o2 = unsigned(2 * sk.y) * W2 + unsigned(2 * sk.x);
+                        float2 s0[4], s1[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int cs = (cl + j < a.cout) ? cl + j : 0;
+                            const float* const ps = a.skip + (size_t(sk.b) * a.skip_ctot + a.skip_coff + cs) * (4u * HWo) + o2;
+                            s0[j] = *reinterpret_cast<const float2*>(ps);
+                            s1[j] = *reinterpret_cast<const float2*>(ps + W2);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (sk.ok && cl + j < a.cout) {
+                                float* const po = a.out + (size_t(sk.b) * a.out_ctot + a.out_coff + cl + j) * (4u * HWo) + o2;
+                                *reinterpret_cast<float2*>(po) = make_float2(v[j] + s0[j].x, v[j] + s0[j].y);
+                                *reinterpret_cast<float2*>(po + W2) = make_float2(v[j] + s1[j].x, v[j] + s1[j].y);
+                            }
                         }
                     }
                 }
-            }
+            });
             return;
         }
     }
@@ -1128,6 +1145,7 @@ int check_variant(mvlm_ctx* ctx, ConvArgs& a, ConvGrid& g) {
     MVLM_REQUIRE(ctx, a.ksize == C::KS, "conv: kernel variant built for another kernel size");
     MVLM_REQUIRE(ctx, a.W % C::TW == 0 && a.H % C::TRI == 0, "conv: spatial size not a multiple of the tile");
     MVLM_REQUIRE(ctx, !C::SPLITK || a.cin_pad % 32 == 0, "conv: split-K tiles need 32-channel chunks");
+    MVLM_REQUIRE(ctx, !(C::SPLITK && C::NT > 1) || (a.kparts <= 1 && !a.amax_val), "conv: the two-column split-K tiles have no K-parts / argmax form");
     MVLM_REQUIRE(ctx, a.cout_pad % C::COUT_T == 0, "conv: cout_pad not a multiple of the cout tile");
     MVLM_REQUIRE(ctx, a.cin_pad % C::CK == 0, "conv: cin_pad must be a multiple of the K-chunk");
     MVLM_REQUIRE(ctx, !a.pre_scale || a.cin_pad <= C::BN_MAXC, "conv: pre-activation BatchNorm supports up to 256 input channels");

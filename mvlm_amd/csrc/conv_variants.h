@@ -58,7 +58,12 @@
 // conv11's parity convolutions of the 84-landmark network on 84 rows (64 + 16 + 4) instead of 96, fused argmax included
 #define MVLM_CONV_VARIANTS_G14(X) \
     X(29, "conv2x2_c84_t8x32", Cfg<84, 32, 8, 1, 2, 4>)
+// split-K tiles with TWO 32-pixel columns per workgroup (round 4): the staged weight slice serves twice the matrix work
+#define MVLM_CONV_VARIANTS_G15(X) \
+    X(30, "conv3x3_sk16_t8x8", Cfg<32, 8, 8, 1, 3, 16, true>) \
+    X(31, "conv3x3_sk8_t8x8", Cfg<32, 8, 8, 1, 3, 8, true>) \
+    X(32, "conv3x3_sk16_t4x16", Cfg<32, 16, 4, 1, 3, 16, true>)
 #define MVLM_CONV_VARIANTS(X) \
-    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X) MVLM_CONV_VARIANTS_G13(X) MVLM_CONV_VARIANTS_G14(X)
-#define MVLM_CONV_N_GROUPS 15
+    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X) MVLM_CONV_VARIANTS_G13(X) MVLM_CONV_VARIANTS_G14(X) MVLM_CONV_VARIANTS_G15(X)
+#define MVLM_CONV_N_GROUPS 16
 #endif
