@@ -586,3 +586,69 @@ def test_draw_table_of_a_new_landmark_count_is_not_overwritten():
         np.random.seed(1)
         out2, _ = e3.estimate_landmarks_from_lines(gmax, s2, e2)
         np.testing.assert_array_equal(got, e3.project_landmarks_to_surface(mesh, out2))
+
+
+# ---- split-K tiles with two 32-pixel columns per workgroup ---------------------------------------------------------------
+@pytest.mark.parametrize("variant,name,cin,cout,size,batch,scatter", [
+    (30, "conv3x3_sk16_t8x8", 256, 128, 16, 3, False), (30, "conv3x3_sk16_t8x8", 128, 64, 32, 2, False), (30, "conv3x3_sk16_t8x8", 64, 64, 8, 5, True),
+    (31, "conv3x3_sk8_t8x8", 256, 128, 32, 1, True), (31, "conv3x3_sk8_t8x8", 64, 64, 16, 7, False), (31, "conv3x3_sk8_t8x8", 128, 64, 8, 2, False),
+    (32, "conv3x3_sk16_t4x16", 256, 128, 16, 5, False), (32, "conv3x3_sk16_t4x16", 128, 64, 32, 1, True),
+])
+def test_two_column_split_k_tiles_match_torch(variant, name, cin, cout, size, batch, scatter):
+    """Round 4: split-K tiles whose four waves multiply TWO 32-pixel columns on one staged weight slice (the small levels are
+    bound by staging weights for 32 pixels of matrix work), forced onto residual-block shaped layers (pre-BN, residual) and,
+    through the network's own executor, onto the scatter form - against torch float64."""
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    assert ctx.lib.mvlm_conv_variant_name(variant).decode() == name
+    rs = np.random.RandomState(cin + size + batch + variant)
+    x = rs.standard_normal((batch, cin, size, size)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    pre = (rs.uniform(0.5, 1.5, cin).astype(np.float32), (rs.standard_normal(cin) * 0.3).astype(np.float32))
+    res = rs.standard_normal((batch, cout, size, size)).astype(np.float32)
+    xd, rd = dev(x), dev(res)
+    yd = torch.empty((batch, cout, size, size), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, variant))
+    try:
+        ctx.check(ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
+                                      p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())))
+        # K parts have no form on these tiles: refused, not mis-run
+        ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, variant + 256))
+        assert ctx.lib.mvlm_conv2d(ctx.handle, C.c_void_p(xd.data_ptr()), batch, cin, size, size, p(w), cout, 3, None,
+                                   p(pre[0]), p(pre[1]), None, None, C.c_void_p(rd.data_ptr()), 0, C.c_void_p(yd.data_ptr())) != 0
+    finally:
+        ctx.check(ctx.lib.mvlm_conv_force_variant(ctx.handle, -1))
+    t = torch.relu(torch.from_numpy(x).double() * torch.from_numpy(pre[0]).double()[None, :, None, None]
+                   + torch.from_numpy(pre[1]).double()[None, :, None, None])
+    want = (torch.nn.functional.conv2d(t, torch.from_numpy(w).double(), None, 1, 1) + torch.from_numpy(res).double()).numpy()
+    assert np.abs(yd.cpu().numpy() - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+
+
+def test_two_column_split_k_tiles_in_the_network():
+    """The same tiles serving every layer they can (plain, scatter and pooled kinds at <= 32x32) inside a forward pass: the
+    heatmaps stay within fp32 rounding of the default dispatch."""
+    from mvlm_amd.prediction import DTU3DPredictor
+
+    imgs = dev(seeded_images(77, 3))
+    pred = DTU3DPredictor(image_mode="RGB", weights="synthetic:6", verbose=False)
+    pred.set_execution(graphs=False, pairing=0)
+    want = pred.heatmaps_device(imgs).clone()
+    ctx, lib = pred.ctx, pred.ctx.lib
+    n = 0
+    for cin, cout in ((256, 128), (128, 64), (64, 64)):
+        for size in (32, 16, 8):
+            for kind in (0, 1, 2):
+                for v in (30, 31, 32):
+                    if lib.mvlm_conv_variant_serves(v, 3, cin, cout, size, kind):
+                        ctx.check(lib.mvlm_conv_set_override(ctx.handle, 3, cin, cout, size, kind, v))
+                        n += 1
+                        break
+    assert n >= 20
+    try:
+        got = pred.heatmaps_device(imgs)
+        assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+        assert not torch.equal(got, want)        # other tiles, another summation order
+    finally:
+        ctx.check(lib.mvlm_conv_set_override(ctx.handle, 0, 0, 0, 0, 0, -1))
+    assert torch.equal(pred.heatmaps_device(imgs), want)

@@ -21,7 +21,7 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))
 HEADER = REPO / "mvlm_amd" / "csrc" / "conv_pair_tuned.h"
-N_VARIANTS = 30
+N_VARIANTS = 33
 # (cin, cout, flags) of a 256-channel residual block's conv1 / conv2 / conv3 (flags: 1 pre-BN, 2 residual + raw copy)
 CONVS = [(256, 128, 3), (128, 64, 3), (64, 64, 3)]
 SIZES = [128, 64, 32, 16, 8]
