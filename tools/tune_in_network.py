@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--out", default=str(REPO / "gpurun_out" / "conv_net_tune.json"))
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--min-gain", type=float, default=0.02)
+    ap.add_argument("--max-size", type=int, default=256, help="only keys of feature maps up to this size (re-tuning the small levels)")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +94,7 @@ def main():
             keys = defaultdict(float)
             current = {}
             for s, v, t, sh in base[0]:
-                if s >= 0 and sh[0] == 3 and not (v & 0x1000) and sh[2] % 32 == 0:
+                if s >= 0 and sh[0] == 3 and not (v & 0x1000) and sh[2] % 32 == 0 and sh[3] <= args.max_size:
                     keys[sh[:5]] += t
                     current[sh[:5]] = v
             gained = 0.0
