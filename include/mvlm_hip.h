@@ -126,7 +126,7 @@ int mvlm_cnn_set_selection(mvlm_ctx* ctx, int method);
  * (what paulsenpredictor.py:187-212 accumulates); used by tests and diagnostics. */
 int mvlm_cnn_heatmaps(mvlm_ctx* ctx, const float* images_dev, int n_views, const int32_t* chan_sel_host,
                       float* heat_dev, void* workspace_dev, size_t workspace_bytes, int batch);
-/* How the ~155 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
+/* How the ~140 launches of a forward pass are issued.  graph_mode 1 (default): a pass over the same buffers and
  * shapes is captured as a hipGraph the second time it is seen and replayed afterwards; 0: always launch by
  * launch.  concurrency: 0 (default, the supported mode) = one stream.  1 = EXPERIMENT ONLY: for batches of <= 32 views
  * the lower hourglass pyramid goes to a second stream beside the 128x128 / 64x64 skip blocks - measured 2-10 % SLOWER
