@@ -160,6 +160,19 @@ def broadcast_int32(arr: np.ndarray | None, shape: tuple, device, src: int = 0, 
     return t.cpu().numpy()
 
 
+def any_rank(flag: bool, device=None) -> bool:
+    """Is ``flag`` set on ANY rank?  (one MAX all-reduce of a scalar; every rank must call it.)  Decisions that change which
+    collectives a rank will issue next - repeating a pass - have to be the same on every rank."""
+    if not is_distributed():
+        return bool(flag)
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_collective_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def all_gather_views(local, n_total: int):
     """local: torch tensor [NL, n_local, 3] on this rank's device -> [NL, n_total, 3] in view order."""
     if not is_distributed():

@@ -118,8 +118,9 @@ class HipPaulsenModel(Predictor2D):
         """"exact" (default): every convolution in exact fp32 on the matrix cores - the path all parity claims are
         about.  Opt-in, fp32-accurate but not bit-identical (argmax near-ties may flip; bench.py reports both separately):
         "fast" - the big 3x3 layers multiply bf16x3-split operands (6 cross products, mvlm_amd/csrc/conv_fast.hip);
-        "fast16" - f16x2-split operands (3 cross products: half the matrix work again).  fp16 overflows at 65520: a pass
-        whose activations get there returns non-finite maxima, and ``predict_device`` / the pipeline repeat it with "fast"."""
+        "fast16" - f16x2-split operands (3 cross products: half the matrix work again).  fp16 ends at 65504: a pass that meets
+        a larger activation is flagged by the kernel (its maxima carry NaN scores), and ``predict_landmarks_from_images`` / the
+        pipeline repeat it with "fast"."""
         if precision not in ("exact", "fast", "fast16"):
             raise ValueError("precision must be 'exact', 'fast' or 'fast16'")
         holders = [self.ctx] + [r.ctx for r in self._replicas]
