@@ -45,4 +45,10 @@ cp $P/kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 cp $P/pmc_summary.txt $OUT/${TAG}_pmc_summary.txt
 cp $P/traffic.json $OUT/${TAG}_traffic.json
 cp $P/bench_trace.json $OUT/${TAG}_bench_under_rocprof.json
+echo "== rocprofv3, the 12-view shard (paired launches, split-K tiles)" ; date
+WORKLOAD="dtu3d-geomdepth-96:12v/gpu" timeout -k 10 900 bash tools/profile_gpu.sh ${TAG}_12views --config dtu3d-geomdepth-96 --views-total 12 > $OUT/profile_log_12views.txt 2>&1 || exit 1
+P=$ROOT/gpurun_out/prof_${TAG}_12views
+cp $P/kernel_stats.csv $OUT/${TAG}_12views_kernel_stats.csv
+cp $P/pmc_summary.txt $OUT/${TAG}_12views_pmc_summary.txt
+cp $P/traffic.json $OUT/${TAG}_12views_traffic.json
 date; ls -la $OUT

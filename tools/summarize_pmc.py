@@ -46,15 +46,10 @@ for k in names[:24]:
 # per-launch HBM traffic of the conv variants, for bench.py's roofline.traffic
 import json
 import re
-VARIANT = {"128, 32, 8, 1, 3, 4": "conv3x3_c128_t8x32", "96, 32, 8, 1, 3, 4": "conv3x3_c96_t8x32",
-           "80, 32, 8, 1, 3, 4": "conv3x3_c80_t8x32", "80, 32, 8, 1, 2, 4": "conv2x2_c80_t8x32",
-           "32, 32, 16, 1, 3, 4": "conv3x3_c32_t16x32",
-           "128, 32, 8, 1, 1, 8": "conv1x1_c128_t8x32", "32, 16, 8, 1, 3, 16": "conv3x3_c32_t8x16",
-           "32, 8, 8, 2, 3, 16": "conv3x3_c32_t8x8x2", "32, 4, 4, 8, 3, 16": "conv3x3_c32_t4x4x8",
-           "128, 32, 4, 1, 3, 4": "conv3x3_c128_t4x32", "64, 32, 4, 1, 3, 4": "conv3x3_c64_t4x32",
-           "64, 32, 8, 1, 3, 4": "conv3x3_c64_t8x32", "96, 32, 8, 1, 2, 4": "conv2x2_c96_t8x32",
-           "32, 16, 2, 1, 3, 32, true": "conv3x3_sk_t2x16", "32, 8, 4, 1, 3, 32, true": "conv3x3_sk_t4x8",
-           "32, 4, 4, 2, 3, 32, true": "conv3x3_sk_t4x4x2", "32, 32, 1, 1, 3, 32, true": "conv3x3_sk_t1x32"}
+# "<template arguments of Cfg>" -> variant name, read from the variant table itself (conv_variants.h)
+VARIANT = {}
+for m in re.finditer(r'X\((\d+), "([^"]+)", Cfg<([^>]*)>\)', (Path(__file__).resolve().parents[1] / "mvlm_amd" / "csrc" / "conv_variants.h").read_text()):
+    VARIANT[m[3]] = m[2]
 traffic = {}
 for k, a in agg.items():
     m = re.search(r"Cfg<([^>]*)>, (true|false)", k)
