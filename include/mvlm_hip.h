@@ -47,6 +47,9 @@ enum { MVLM_MAXIMA_SIMPLE = 0, MVLM_MAXIMA_MOMENT = 1 };   /* paulsenpredictor.p
 int mvlm_ctx_create(int device, mvlm_ctx** out);
 void mvlm_ctx_destroy(mvlm_ctx* ctx);
 const char* mvlm_last_error(mvlm_ctx* ctx);
+/* the stream the context's next calls enqueue on (default: the null stream).  A context reuses device scratch from call to
+ * call; when the stream CHANGES, the new stream is made to wait for what the context enqueued on the previous one, so two
+ * users of one context under different streams stay ordered. */
 int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream);
 int mvlm_synchronize(mvlm_ctx* ctx);
 /* name of the GPU architecture the library was built for ("gfx950") */

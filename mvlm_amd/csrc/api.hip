@@ -52,6 +52,7 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
     if (ctx->cnn.fast_blob) hipFree(ctx->cnn.fast_blob);
     if (ctx->cnn.fast16_blob) hipFree(ctx->cnn.fast16_blob);
     if (ctx->cnn.fast16_flag) hipFree(ctx->cnn.fast16_flag);
+    if (ctx->switch_event) hipEventDestroy(ctx->switch_event);
     for (int i = 0; i < 2; ++i) {
         if (ctx->kparts_ws[i]) hipFree(ctx->kparts_ws[i]);
         if (ctx->kparts_cnt[i]) hipFree(ctx->kparts_cnt[i]);
@@ -93,9 +94,22 @@ extern "C" const char* mvlm_last_error(mvlm_ctx* ctx) {
     return mvlm_thread_error().c_str();
 }
 
+// A context owns grow-only scratch (render bins and keys, transformed vertices, fusion staging) that its kernels reuse from
+// call to call: safe while the calls are ordered on one stream.  Callers that move a context to ANOTHER stream (two
+// pipelines of one device under different torch streams share the process-wide context) get that order kept for them: the
+// new stream waits for everything the context enqueued on the previous one.
 extern "C" int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream) {
     MVLM_ENTER(ctx);
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next != ctx->stream && ctx->work_enqueued) {
+        if (!ctx->switch_event) MVLM_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
+        if (hipEventRecord(ctx->switch_event, ctx->stream) == hipSuccess)
+            MVLM_CHECK_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_event, 0));
+        else
+            (void)hipGetLastError();  // the previous stream no longer exists (its owner destroyed it): its work is done
+    }
+    ctx->stream = next;
+    ctx->work_enqueued = true;  // (whoever sets a stream is about to enqueue on it)
     return 0;
 }
 

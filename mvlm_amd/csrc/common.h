@@ -212,6 +212,8 @@ struct mvlm_ctx {
     // its side stream while it issues the branch of the graph that runs beside the main one (cnn_graph.hip)
     hipStream_t launch_stream = nullptr;
     hipStream_t cur_stream() const { return launch_stream ? launch_stream : stream; }
+    hipEvent_t switch_event = nullptr;  // mvlm_set_stream: orders the context's work across a change of stream
+    bool work_enqueued = false;
     std::mutex mu;
     std::string err;
     CnnState cnn;

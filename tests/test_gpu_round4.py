@@ -652,3 +652,29 @@ def test_two_column_split_k_tiles_in_the_network():
     finally:
         ctx.check(lib.mvlm_conv_set_override(ctx.handle, 0, 0, 0, 0, 0, -1))
     assert torch.equal(pred.heatmaps_device(imgs), want)
+
+
+def test_one_context_under_two_streams_stays_ordered():
+    """Two users of the process-wide renderer context under different torch streams (two pipelines of one device): the
+    context's scratch (bins, keys, transformed vertices) is reused from call to call, so mvlm_set_stream makes the new stream
+    wait for the work enqueued on the previous one.  Renders issued alternately on two streams, without any host wait in
+    between, equal the renders issued one after the other."""
+    from mvlm_amd.utils import HipRenderer3D
+    from mvlm_amd.utils.synthetic import face_like_mesh
+
+    r = HipRenderer3D(n_views=24, verbose=False)
+    meshes = [face_like_mesh(120, 64, 3), face_like_mesh(90, 64, 4)]
+    np.random.seed(3)
+    poses = r.generate_3d_transformations()
+    want = [r.render_device(m, poses).clone() for m in meshes]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(6):
+        for m, st in zip(meshes, (s1, s2)):
+            with torch.cuda.stream(st):
+                outs.append((rep, r.render_device(m, poses)))
+    torch.cuda.synchronize()
+    for k, (rep, o) in enumerate(outs):
+        assert torch.equal(o, want[k % 2]), (rep, k % 2)
+    r.check()
