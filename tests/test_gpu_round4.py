@@ -678,3 +678,42 @@ def test_one_context_under_two_streams_stays_ordered():
     for k, (rep, o) in enumerate(outs):
         assert torch.equal(o, want[k % 2]), (rep, k % 2)
     r.check()
+
+
+def test_new_entry_points_refuse_bad_arguments():
+    """The round's C entry points report misuse through the status code and mvlm_last_error (nothing throws, nothing is launched)."""
+    from mvlm_amd import _lib, weights
+    from mvlm_amd.prediction import DTU3DPredictor
+
+    fresh = _lib.Context(0)
+    lib = fresh.lib
+    assert lib.mvlm_cnn_set_selection(fresh.handle, 1) != 0 and b"mvlm_cnn_load comes first" in lib.mvlm_last_error(fresh.handle)
+    assert lib.mvlm_cnn_set_pairing(fresh.handle, 3) != 0 and lib.mvlm_cnn_set_pairing(fresh.handle, -1) != 0
+    assert lib.mvlm_cnn_set_precision(fresh.handle, 2) != 0 and b"load_fast16" in lib.mvlm_last_error(fresh.handle)
+    v = C.c_int(7)
+    assert lib.mvlm_cnn_fast16_overflowed(fresh.handle, C.byref(v)) == 0 and v.value == 0   # nothing loaded: nothing overflowed
+    assert lib.mvlm_cnn_fast16_overflowed(fresh.handle, None) != 0
+    # overrides: a variant that cannot serve the shape is refused, a serving one accepted, ksize 0 clears
+    assert lib.mvlm_conv_set_override(fresh.handle, 3, 256, 128, 16, 0, 0) != 0            # 8x32-pixel tiles on a 16x16 map
+    assert lib.mvlm_conv_set_override(fresh.handle, 3, 256, 128, 16, 0, 30) == 0
+    assert lib.mvlm_conv_set_override(fresh.handle, 3, 256, 128, 16, 0, 30 + 256) != 0     # no K parts on the two-column tiles
+    assert lib.mvlm_conv_set_override(fresh.handle, 0, 0, 0, 0, 0, -1) == 0
+    assert lib.mvlm_conv_variant_serves(16, 3, 256, 80, 128, 0) == 0                       # the 80-row tile is conv6 / conv10's alone
+    assert lib.mvlm_conv_variant_serves(0, 3, 256, 128, 128, 2) == 1 and lib.mvlm_conv_variant_serves(0, 1, 64, 128, 256, 0) == 0
+    fresh.close()
+    pred = DTU3DPredictor(image_mode="RGB", weights="synthetic:2", verbose=False)
+    ctx = pred.ctx
+    assert lib.mvlm_cnn_set_selection(ctx.handle, 2) != 0 and lib.mvlm_cnn_set_selection(ctx.handle, 1) == 0 and lib.mvlm_cnn_set_selection(ctx.handle, 0) == 0
+    blob, off, unscale = weights.pack_fast16_for_device(pred._state_dict, 73, 3, pred._desc)
+    bad = unscale.copy()
+    bad[int(np.argmax(off >= 0))] = 0.0
+    q16 = blob.ctypes.data_as(C.POINTER(C.c_uint16))
+    assert lib.mvlm_cnn_load_fast16(ctx.handle, q16, blob.size, off.ctypes.data_as(C.POINTER(C.c_int64)), p(bad), off.shape[0]) != 0
+    assert b"inverse scale" in lib.mvlm_last_error(ctx.handle)
+    assert lib.mvlm_cnn_load_fast16(ctx.handle, q16, blob.size - 8, off.ctypes.data_as(C.POINTER(C.c_int64)), p(unscale), off.shape[0]) != 0
+    assert lib.mvlm_cnn_load_fast16(ctx.handle, q16, blob.size, off.ctypes.data_as(C.POINTER(C.c_int64)), p(unscale), off.shape[0]) == 0
+    # the packer refuses non-finite weights (their scale would be meaningless)
+    w = np.ones((64, 16, 3, 3), np.float32)
+    w[0, 0, 0, 0] = np.inf
+    out = np.empty(int(lib.mvlm_pack_fast_weights16(p(w), 64, 16, 64, 16, None, None)), np.uint16)
+    assert lib.mvlm_pack_fast_weights16(p(w), 64, 16, 64, 16, out.ctypes.data_as(C.POINTER(C.c_uint16)), None) == 0
