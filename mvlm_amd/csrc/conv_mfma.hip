@@ -347,7 +347,7 @@ extern "C" int mvlm_conv_variant_serves(int variant, int ksize, int cin_pad, int
         if (V::KS != 3 || V::TAIL16 || V::COUT_T == 96) return 0;                                                            \
         if (size % V::TW != 0 || size % V::TRI != 0 || cout_pad % V::COUT_T != 0 || cin_pad % V::CK != 0) return 0;          \
         if (V::SPLITK && cin_pad % 32 != 0) return 0;                                                                        \
-        if (parts > 1 && (!V::SPLITK || cin_pad % (parts * V::CK) != 0)) return 0;                                           \
+        if (parts > 1 && (!V::SPLITK || V::PIX_T != 32 || cin_pad % (parts * V::CK) != 0)) return 0;                         \
         return 1;                                                                                                            \
     }
         MVLM_CONV_VARIANTS(X)
