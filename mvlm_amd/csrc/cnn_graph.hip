@@ -264,7 +264,6 @@ struct Exec {
         Tensor x, y, t1, t2;
         Tensor* pooled = nullptr;
         ConvArgs ar, a[3];   // the 1x1 resample (when present), conv1..conv3
-        const Tensor* in[3] = {nullptr, nullptr, nullptr};
         bool want_pool = false, keep_full = true;
     };
     RbPlan plan_rb(int rb_index, const Tensor& x, Tensor* hi, Tensor* pooled = nullptr, bool keep_full = true) {
