@@ -387,10 +387,12 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
     ctx->conv_force_variant = variant >= 0 ? variant : (variant == -2 ? -2 : -1);
     int used = -1;
     unsigned short* wq = nullptr;
-    if (variant == MVLM_CONV_VARIANT_FAST) {  // the opt-in bf16x3 kernel on zero weights (cin_pad must be a multiple of 16)
+    // the opt-in split kernels on zero weights: 62 bf16x3, 61 f16x2
+    const int splits = variant == MVLM_CONV_VARIANT_FAST ? 3 : (variant == MVLM_CONV_VARIANT_FAST16 ? 2 : 0);
+    if (splits) {
         a.cin_pad = (cin + 15) / 16 * 16;
         a.cout_pad = (cout + 63) / 64 * 64;
-        const size_t n16 = size_t(a.cin_pad / 16) * 9 * 2 * 3 * a.cout_pad * 8;
+        const size_t n16 = size_t(a.cin_pad / 16) * 9 * 2 * splits * a.cout_pad * 8;
         wq = static_cast<unsigned short*>(ctx->get_scratch("conv_bench.wq", n16 * 2));
         if (!wq || !mvlm_conv_fast_ok(a)) {
             ctx->conv_force_variant = saved;
@@ -398,7 +400,7 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
         }
         (void)hipMemsetAsync(wq, 0, n16 * 2, ctx->stream);
     }
-    auto launch = [&](int* v) { return wq ? mvlm_launch_conv_fast(ctx, a, wq) : mvlm_launch_conv(ctx, a, v); };
+    auto launch = [&](int* v) { return wq ? mvlm_launch_conv_fast(ctx, a, wq, splits, 1.f) : mvlm_launch_conv(ctx, a, v); };
     int rc = launch(&used);  // warm-up (also sets the launch attributes)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = ctx->fail("conv_bench: hipEventCreate failed");

@@ -45,6 +45,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
 namespace {
 
@@ -59,30 +63,22 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ unsigned bf16_bits(float x) {
-    const __bf16 h = static_cast<__bf16>(x);  // round to nearest even (v_cvt_pk_bf16_f32)
-    unsigned short b;
-    __builtin_memcpy(&b, &h, 2);
-    return b;
+// Two values at a time (one 32-bit register per split term; element 0 in the low half):
+// x -> (h, m, l) bf16 with h + m + l == x up to 2^-24 |x| (round to nearest even, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned* h, unsigned* m, unsigned* l) {
+    *h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+    const float r0 = x0 - __uint_as_float(*h << 16), r1 = x1 - __uint_as_float(*h & 0xFFFF0000u);
+    *m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+    const float s0 = r0 - __uint_as_float(*m << 16), s1 = r1 - __uint_as_float(*m & 0xFFFF0000u);
+    *l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
 }
-__device__ __forceinline__ float bf16_value(unsigned b) { return __uint_as_float(b << 16); }
-
-// x -> (h, m, l) bf16 bit patterns with h + m + l == x up to 2^-24 |x|
-__device__ __forceinline__ void split3(float x, unsigned* h, unsigned* m, unsigned* l) {
-    *h = bf16_bits(x);
-    const float r1 = x - bf16_value(*h);
-    *m = bf16_bits(r1);
-    const float r2 = r1 - bf16_value(*m);
-    *l = bf16_bits(r2);
-}
-
-// x -> (h, l) fp16 bit patterns with |x - (h + l)| <= max(2^-22 |x|, 2^-25); |x| >= 65520 gives h = +-inf
-__device__ __forceinline__ void split2(float x, unsigned* h, unsigned* l) {
-    const _Float16 hh = static_cast<_Float16>(x);  // round to nearest even (v_cvt_f16_f32)
-    const float r = x - static_cast<float>(hh);
-    const _Float16 ll = static_cast<_Float16>(r);
-    *h = __builtin_bit_cast(unsigned short, hh);
-    *l = __builtin_bit_cast(unsigned short, ll);
+// x -> (h, l) fp16 with |x - (h + l)| <= max(2^-22 |x|, 2^-25); |x| >= 65520 gives h = +-inf (the epilogue sees what that does)
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned* h, unsigned* l) {
+    const f16x2 hh = __builtin_convertvector((f32x2){x0, x1}, f16x2);  // round to nearest even
+    // x - float(h), exactly that (one rounding), as an fma so that the fp16 operand converts inside the instruction
+    const float r0 = __builtin_fmaf(static_cast<float>(hh.x), -1.f, x0), r1 = __builtin_fmaf(static_cast<float>(hh.y), -1.f, x1);
+    *h = __builtin_bit_cast(unsigned, hh);
+    *l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, f16x2));
 }
 
 // the arithmetic of a split: NS terms per operand, the cross terms (weight term, activation term) smallest first
@@ -114,7 +110,7 @@ struct FastCfg {
     static constexpr int W_ITEMS = W_BYTES / 16, W_ITERS = (W_ITEMS + FT_THREADS - 1) / FT_THREADS;
     static constexpr int X_ITEMS = 2 * NPIX, X_ITERS = (X_ITEMS + FT_THREADS - 1) / FT_THREADS;
     static constexpr int TAP_MFMAS = Split<NS>::NTERMS * MT * NT;  // per tap and wave
-    static constexpr size_t LDS = size_t(2) * X_BYTES + size_t(2) * W_BYTES + 2 * 256 * sizeof(float);
+    static constexpr size_t LDS = size_t(2) * X_BYTES + size_t(2) * W_BYTES + 4 * 256 * sizeof(float);  // + BatchNorm table + as many zeros
     static_assert(LDS <= 160 * 1024, "stages must fit the CU's LDS");
     static_assert(TAP_MFMAS == (NS == 3 ? 24 : 12), "the staging schedules below are written for 24 (bf16x3) / 12 (f16x2) MFMAs per tap");
     static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
@@ -133,7 +129,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fast[];
     unsigned char* const sX = smem_fast;                        // 2 stages
     unsigned char* const sW = smem_fast + 2 * X_BYTES;          // 2 stages
-    float* const sbn = reinterpret_cast<float*>(sW + 2 * W_BYTES);  // [2][256]
+    float* const sbn = reinterpret_cast<float*>(sW + 2 * W_BYTES);  // [128 channel pairs][scale, scale, shift, shift], then 512 zeros
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int wm = wave & 1, wn = wave >> 1;
@@ -155,95 +151,116 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
 
     // ---- staging plans ------------------------------------------------------------------------------------------
     // X: item e -> (k-half kh, haloed pixel p); eight channels 16 chunk + 8 kh + j of that pixel
-    unsigned xoff[X_ITERS];   // element offset of channel (8 kh) of chunk 0 at that pixel, or ~0u outside the image
-    int xdst[X_ITERS];        // byte offset inside an X stage of split 0 (+ NPIX * 16 per split), < 0: no item
-    int xkh[X_ITERS];
+    // Every thread stages X_ITERS items whether or not that many exist: an item past the end repeats the thread's item 0
+    // (same loads, same LDS writes - no conditional code in the main loop), a pixel outside the image reads its BatchNorm
+    // parameters from the table of zeros (0 * x + 0, whatever was loaded from the clamped address: zero padding).
+    unsigned xoff[X_ITERS];   // element offset of channel (8 kh) of chunk 0 at that pixel
+    int xdst[X_ITERS];        // byte offset inside an X stage of split 0 (+ NPIX * 16 per split)
+    int xbn[X_ITERS];         // float offset of the item's BatchNorm parameters for chunk 0 in sbn
 #pragma unroll
     for (int i = 0; i < X_ITERS; ++i) {
-        const int e = tid + i * FT_THREADS;
+        const int e0 = tid + i * FT_THREADS, e = e0 < X_ITEMS ? e0 : tid;
         const int kh = e / NPIX, p = e - kh * NPIX;
         const int yy = p / FT_PW, xx = p - yy * FT_PW;
         const int y = y0 + yy - 1, x = x0 + xx - 1;
-        const bool ok = e < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
-        xoff[i] = ok ? (unsigned(b0 * a.in_ctot + a.in_coff + 8 * kh) * HW + unsigned(y * W + x)) : 0xFFFFFFFFu;
-        xdst[i] = e < X_ITEMS ? (kh * NS * NPIX + p) * 16 : -1;
-        xkh[i] = kh;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        xoff[i] = unsigned(b0 * a.in_ctot + a.in_coff + 8 * kh) * HW + (ok ? unsigned(y * W + x) : 0u);
+        xdst[i] = (kh * NS * NPIX + p) * 16;
+        xbn[i] = 16 * kh + (ok ? 0 : 512);
     }
     // W: item f -> segment (tap, kh, split) and output channel c of the tile; linear in the host layout
     unsigned wsrc[W_ITERS];   // u16 element offset inside a (chunk, tap row) block of the packed weights
+    int wdst[W_ITERS];
 #pragma unroll
     for (int i = 0; i < W_ITERS; ++i) {
-        const int f = tid + i * FT_THREADS;
+        const int f0 = tid + i * FT_THREADS, f = f0 < W_ITEMS ? f0 : tid;
         const int seg = f / COUT_T, c = f - seg * COUT_T;
-        wsrc[i] = f < W_ITEMS ? unsigned((seg * a.cout_pad + co0 + c) * 8) : 0xFFFFFFFFu;
+        wsrc[i] = unsigned((seg * a.cout_pad + co0 + c) * 8);
+        wdst[i] = f * 16;
     }
     const size_t w_block = size_t(6 * NS) * a.cout_pad * 8;  // u16 elements of one (chunk, tap row) block
 
-    // f16x2 only: has this thread seen an activation outside fp16's range?  The non-finite products it causes do NOT reliably
-    // reach the output (the next layer's ReLU is a v_max, which drops a NaN), so the kernel raises a flag word instead; the
-    // executor turns the pass's maxima into NaN when it is set (cnn_graph.hip) and the caller repeats the pass on bf16x3.
-    bool ovf = false;
-    float xv[X_ITERS][8];      // the next chunk's activations, in flight / waiting for their split
-    unsigned xq[NS][4];        // one item's eight channels as 16-bit pairs, per split
-    u32x4 wv[W_ITERS];         // the next tap row's weights
+    float xv[X_ITERS][8];      // activations in flight / waiting for their split
+    u32x4 xq[NS];              // one item's eight channels as 16-bit pairs, per split
+    u32x4 wv[W_ITERS];         // weights in flight
+    const float relu_floor = has_bn ? 0.f : -__builtin_inff();  // no BatchNorm in front: no ReLU either
+    const int last_unit = 3 * n_chunks - 1;
 
-    // ---- staging micro-operations (each one small enough for the shadow of one or two MFMAs) --------------------------
+    // ---- staging micro-operations (each one small enough for the shadow of one or two MFMAs).  None of them is conditional
+    // on "is there a next stage": past the end they load the last stage again and write the LDS stage nobody reads any more.
     auto load_w = [&](int unit) __attribute__((always_inline)) {
-        const unsigned short* const wb = wq + size_t(unit) * w_block;
+        const unsigned short* const wb = wq + size_t(unit < last_unit ? unit : last_unit) * w_block;
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i)
-            wv[i] = *reinterpret_cast<const u32x4*>(wb + (wsrc[i] != 0xFFFFFFFFu ? wsrc[i] : 0u));
+#if defined(MVLM_FAST_ABLATE_NO_W)  // timing experiment only
+            if (unit < 2)
+#endif
+            wv[i] = *reinterpret_cast<const u32x4*>(wb + wsrc[i]);
     };
     auto store_w = [&](auto ic, int unit) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        const int f = tid + i * FT_THREADS;
-        if (f < W_ITEMS) *reinterpret_cast<u32x4*>(sW + (unit & 1) * W_BYTES + f * 16) = wv[i];
+#if defined(MVLM_FAST_ABLATE_NO_W)
+        if (unit < 2)
+#endif
+        *reinterpret_cast<u32x4*>(sW + (unit & 1) * W_BYTES + wdst[i]) = wv[i];
     };
-    auto load_x = [&](int chunk) __attribute__((always_inline)) {
-        const float* const base = a.in + size_t(chunk) * 16 * HW;
-#pragma unroll
-        for (int i = 0; i < X_ITERS; ++i)
+    auto load_x_item = [&](auto ic, int chunk_) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < X_ITERS) {
+            const int chunk = chunk_ < n_chunks ? chunk_ : n_chunks - 1;
+            const float* const base = a.in + size_t(chunk) * 16 * HW;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bool ok = xoff[i] != 0xFFFFFFFFu && (!partial_cin || chunk * 16 + 8 * xkh[i] + j < a.cin);
-                xv[i][j] = base[ok ? xoff[i] + unsigned(j) * HW : 0u];  // branch-free; what is not there is zeroed in convert_pair
+                const bool ok = !partial_cin || chunk * 16 + ((xbn[i] & 16) >> 1) + j < a.cin;
+#if defined(MVLM_FAST_ABLATE_NO_XLOAD)  // timing experiment only
+                if (chunk_ < 2)
+#endif
+                xv[i][j] = base[ok ? xoff[i] + unsigned(j) * HW : 0u];  // what is not there is zeroed in convert_pair
             }
+        }
     };
-    // BatchNorm + ReLU, zero padding, split: channels 2 jp and 2 jp + 1 of item i -> one u32 per split
+    auto load_x = [&](int chunk) __attribute__((always_inline)) {
+        static_for<0, X_ITERS>([&](auto ic) { load_x_item(ic, chunk); });
+    };
+    // BatchNorm + ReLU, split: channels 2 jp and 2 jp + 1 of item i -> one u32 per split
     auto convert_pair = [&](auto ic, auto jc, int chunk) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, jp = decltype(jc)::value;
-        unsigned h[2], m[2], l[2];
-        const int c = chunk * 16 + 8 * xkh[i] + 2 * jp;
-        float2 sc = make_float2(1.f, 1.f), sh = make_float2(0.f, 0.f);
-        if (has_bn) {
-            sc = *reinterpret_cast<const float2*>(sbn + c);
-            sh = *reinterpret_cast<const float2*>(sbn + 256 + c);
+        if constexpr (i < X_ITERS) {
+            const int c = chunk * 16 + ((xbn[i] & 16) >> 1) + 2 * jp;  // (xbn = 16 kh [+ 512])
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(sbn + chunk * 32 + xbn[i] + 4 * jp);  // scale, scale, shift, shift of channels c, c + 1
+            float v0 = fmaxf(fmaf(xv[i][2 * jp], bn.x, bn.z), relu_floor);
+            float v1 = fmaxf(fmaf(xv[i][2 * jp + 1], bn.y, bn.w), relu_floor);
+            if (partial_cin) {  // channels past cin
+                v0 = c < a.cin ? v0 : 0.f;
+                v1 = c + 1 < a.cin ? v1 : 0.f;
+            }
+#if defined(MVLM_FAST_ABLATE_NO_CONVERT)  // timing experiment only
+            xq[0][jp] = __float_as_uint(xv[i][2 * jp]);
+            xq[1][jp] = __float_as_uint(xv[i][2 * jp + 1]);
+            if constexpr (NS == 3) xq[NS - 1][jp] = __float_as_uint(xv[i][2 * jp]) ^ 1u;
+            return;
+#endif
+            if constexpr (NS == 3) {
+                unsigned h, m, l;
+                split3_pair(v0, v1, &h, &m, &l);
+                xq[0][jp] = h;
+                xq[1][jp] = m;
+                xq[2][jp] = l;
+            } else {
+                unsigned h, l;
+                split2_pair(v0, v1, &h, &l);
+                xq[0][jp] = h;
+                xq[1][jp] = l;
+            }
         }
-        const bool inside = xoff[i] != 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float v = xv[i][2 * jp + k];
-            if (has_bn) v = fmaxf(fmaf(v, k ? sc.y : sc.x, k ? sh.y : sh.x), 0.f);
-            v = inside && (!partial_cin || c + k < a.cin) ? v : 0.f;  // zero padding after the activation; channels past cin
-            if constexpr (NS == 2) ovf |= !(fabsf(v) < 65504.f);         // beyond fp16 (or NaN): the pass is flagged, see below
-            if constexpr (NS == 3)
-                split3(v, &h[k], &m[k], &l[k]);
-            else
-                split2(v, &h[k], &l[k]);
-        }
-        xq[0][jp] = h[0] | (h[1] << 16);
-        if constexpr (NS == 3) xq[1][jp] = m[0] | (m[1] << 16);
-        xq[NS - 1][jp] = l[0] | (l[1] << 16);
     };
     auto store_x = [&](auto ic, auto sc, int chunk) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, sp = decltype(sc)::value;
-        if (xdst[i] >= 0) {
-            u32x4 r;
-            r.x = xq[sp][0];
-            r.y = xq[sp][1];
-            r.z = xq[sp][2];
-            r.w = xq[sp][3];
-            *reinterpret_cast<u32x4*>(sX + (chunk & 1) * X_BYTES + xdst[i] + sp * NPIX * 16) = r;
+        if constexpr (i < X_ITERS) {
+#if defined(MVLM_FAST_ABLATE_NO_XSTORE)  // timing experiment only
+            if (xdst[i] == -2)
+#endif
+            *reinterpret_cast<u32x4*>(sX + (chunk & 1) * X_BYTES + xdst[i] + sp * NPIX * 16) = xq[sp];
         }
     };
     // all of item i at once (prologue)
@@ -270,30 +287,39 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     for (int m = 0; m < MT; ++m) aoff[m] = (half * NS * COUT_T + wm * 32 * MT + 32 * m + l31) * 16;
 
     // ---- prologue: BatchNorm table, chunk 0's activations, unit 0's weights ----------------------------------------------
-    if (has_bn)
-        for (int i = tid; i < a.cin_pad; i += FT_THREADS) {  // padding channels: relu(0 * 0 + 0) = 0
-            sbn[i] = i < a.cin ? a.pre_scale[i] : 0.f;
-            sbn[256 + i] = i < a.cin ? a.pre_shift[i] : 0.f;
-        }
+    // [channel pair][scale, scale, shift, shift]; without BatchNorm: 1, 0 (and no ReLU: relu_floor); then the zeros
+    for (int i = tid; i < 256; i += FT_THREADS) {  // padding channels: relu(0 * 0 + 0) = 0
+        const bool there = has_bn && i < a.cin;
+        sbn[4 * (i >> 1) + (i & 1)] = there ? a.pre_scale[i] : (has_bn || i >= a.cin_pad ? 0.f : 1.f);
+        sbn[4 * (i >> 1) + 2 + (i & 1)] = there ? a.pre_shift[i] : 0.f;
+        sbn[512 + i] = 0.f;
+        sbn[768 + i] = 0.f;
+    }
     load_w(0);
     load_x(0);
     __syncthreads();  // BatchNorm table visible
     static_for<0, W_ITERS>([&](auto ic) { store_w(ic, 0); });
     static_for<0, X_ITERS>([&](auto ic) { stage_item(ic, 0); });
+    // (in the order the main loop leaves its loads in flight at the end of a chunk: the wait counters the compiler places
+    // at the top of the loop then fit both ways in)
+    load_x_item(std::integral_constant<int, 0>{}, 1);
+    load_w(1);
+    static_for<1, X_ITERS>([&](auto ic) { load_x_item(ic, 1); });
     __syncthreads();
 
-    // One unit = (chunk, tap row ROW): 3 taps x 24 MFMAs per wave.  The staging of what comes next is cut into
+    // One unit = (chunk, tap row ROW): 3 taps x 24 (12) MFMAs per wave.  The staging of what comes next is cut into
     // micro-operations placed BETWEEN the MFMAs (slot q = 24 tap + index): the matrix pipe holds a wave's vector issue
     // for 8 of an MFMA's 32 cycles, the rest is where BatchNorm / split / LDS writes of the next stage run.
-    //   every unit : global loads of the next unit's weights at q = 0, their LDS writes at q = 24 + 4 i (tap 1)
-    //   ROW == 0   : global loads of the NEXT chunk's activations at q = 1 (two units of lead)
-    //   ROW == 1   : item 0 of the next chunk: pairs at q = 2, 8, 14, 20, splits stored at q = 44, 50, 56
-    //   ROW == 2   : item 1: pairs at q = 2, 6, 10, 14, stores at q = 18, 20, 22; item 2: pairs at q = 28, 32, 36, 40,
-    //                stores at q = 60, 64, 68
+    // Global loads run TWO stages ahead, each into the registers the previous stage has just been converted / stored from,
+    // so a load has a unit or more (the activations: three) to arrive before anything waits for it:
+    //   every unit : LDS writes of the next unit's weights at q = 24 + 4 i (tap 1), then the loads of the unit after it
+    //   ROW == 1   : item 0 of the next chunk: pairs at q = 2, 8, 14, 20, then its loads of the chunk after; splits stored
+    //                at q = 44, 50, 56
+    //   ROW == 2   : item 1: pairs at q = 2, 6, 10, 14 (+ loads), stores at q = 18, 20, 22; item 2: pairs at q = 28, 32, 36, 40
+    //                (+ loads), stores at q = 60, 64, 68                                     (72-slot table; the 36-slot one below)
     auto unit = [&](auto rowc, int chunk) __attribute__((always_inline)) {
         constexpr int ROW = decltype(rowc)::value;
         const int u = 3 * chunk + ROW;
-        const bool more_w = u + 1 < 3 * n_chunks, more_x = chunk + 1 < n_chunks;
         const unsigned char* const xs = sX + (chunk & 1) * X_BYTES;
         const unsigned char* const ws = sW + (u & 1) * W_BYTES;
         frag_t af[MT][NS], bf[NT][NS];
@@ -323,18 +349,25 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
 #else
                 if constexpr (q >= 0) {
 #endif
-                if constexpr (q == 0) {
-                    if (more_w) load_w(u + 1);
-                }
-                if constexpr (q == 1 && ROW == 0) {
-                    if (more_x) load_x(chunk + 1);
-                }
                 // slot tables: bf16x3 has 72 slots per unit, f16x2 has 36 - the same micro-operations (one split fewer) at
                 // half the distance.  W stores in tap 1; item 0 during ROW 1; items 1 and 2 during ROW 2; an item's splits are
                 // stored after its four channel pairs have been converted, the next item's conversion starts after that.
                 constexpr int WQ0 = NS == 3 ? 24 : 12, WQS = NS == 3 ? 4 : 2;
                 if constexpr (q >= WQ0 && q < WQ0 + WQS * W_ITERS && (q - WQ0) % WQS == 0) {
-                    if (more_w) store_w(std::integral_constant<int, (q - WQ0) / WQS>{}, u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_w(std::integral_constant<int, (q - WQ0) / WQS>{}, u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // Loads complete in order: a wait for the weights also waits for every OLDER load.  The activations come from HBM
+                // and take several times as long as the weights (L2), so in every unit the weight loads are issued first and
+                // the activation loads behind them - a weight wait then leaves them in flight.
+                constexpr int WL = WQ0 + WQS * (W_ITERS - 1) + 1, XL = WL + 1;
+                // (the scheduler is told to leave the loads and the weights' LDS writes in their slots: left alone it sinks
+                // the loads to the end of the unit, which halves the time they have to arrive)
+                if constexpr (q == WL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w(u + 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 constexpr int C0 = NS == 3 ? 2 : 1, C0S = NS == 3 ? 6 : 3;      // ROW 1, item 0: pairs at C0 + C0S j
                 constexpr int S0 = NS == 3 ? 44 : 20, S0S = NS == 3 ? 6 : 4;    //               stores at S0 + S0S sp
@@ -344,32 +377,49 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 constexpr int S2 = NS == 3 ? 60 : 28, S2S = NS == 3 ? 4 : 2;
                 if constexpr (ROW == 1) {
                     if constexpr (q >= C0 && q < C0 + 4 * C0S && (q - C0) % C0S == 0) {
-                        if (more_x) convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - C0) / C0S>{}, chunk + 1);
+                        convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - C0) / C0S>{}, chunk + 1);
+                    }
+                    if constexpr (q == (C0 + 3 * C0S + 1 > XL ? C0 + 3 * C0S + 1 : XL)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_x_item(std::integral_constant<int, 0>{}, chunk + 2);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (q >= S0 && q < S0 + NS * S0S && (q - S0) % S0S == 0) {
-                        if (more_x) store_x(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - S0) / S0S>{}, chunk + 1);
+                        store_x(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - S0) / S0S>{}, chunk + 1);
                     }
                 }
                 if constexpr (ROW == 2 && X_ITERS >= 2) {
                     if constexpr (q >= C1 && q < C1 + 4 * C1S && (q - C1) % C1S == 0) {
-                        if (more_x) convert_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - C1) / C1S>{}, chunk + 1);
+                        convert_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - C1) / C1S>{}, chunk + 1);
+                    }
+                    if constexpr (q == (C1 + 3 * C1S + 1 > XL ? C1 + 3 * C1S + 1 : XL)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_x_item(std::integral_constant<int, 1>{}, chunk + 2);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (q >= S1 && q < S1 + NS * S1S && (q - S1) % S1S == 0) {
-                        if (more_x) store_x(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - S1) / S1S>{}, chunk + 1);
+                        store_x(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - S1) / S1S>{}, chunk + 1);
                     }
                 }
                 if constexpr (ROW == 2 && X_ITERS >= 3) {
                     if constexpr (q >= C2 && q < C2 + 4 * C2S && (q - C2) % C2S == 0) {
-                        if (more_x) convert_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - C2) / C2S>{}, chunk + 1);
+                        convert_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - C2) / C2S>{}, chunk + 1);
+                    }
+                    if constexpr (q == (C2 + 3 * C2S + 1 > XL + 1 ? C2 + 3 * C2S + 1 : XL + 1)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_x_item(std::integral_constant<int, 2>{}, chunk + 2);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (q >= S2 && q < S2 + NS * S2S && (q - S2) % S2S == 0) {
-                        if (more_x) store_x(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - S2) / S2S>{}, chunk + 1);
+                        store_x(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - S2) / S2S>{}, chunk + 1);
                     }
                 }
                 }
             });
         });
+#if !defined(MVLM_FAST_ABLATE_NO_BARRIER)  // timing experiment only
         __syncthreads();
+#endif
     };
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         unit(std::integral_constant<int, 0>{}, chunk);
@@ -380,6 +430,11 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     // ---- epilogue: bias, post-BatchNorm + ReLU, raw copy, residual, store -----------------------------------------------
     // One MFMA tile row (32 channels x NT row segments) at a time: all its residual values are requested first, then
     // the stores follow; the layer kinds that carry the time run without per-element feature tests.
+    // f16x2: an activation beyond fp16's range went in as +-inf; every product with it, hence every output whose window
+    // holds it, is inf or NaN.  That does NOT reliably survive the network (the next layer's ReLU is a v_max, which drops a
+    // NaN), so the kernel raises the context's flag word; the executor turns the pass's maxima into NaN when it is set
+    // (cnn_graph.hip) and the caller repeats the pass on bf16x3.
+    float finite_chk = 0.f;
     auto epilogue = [&](auto raw_c, auto res_c, auto par_c) __attribute__((always_inline)) {
         constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value;
         constexpr int PAR = decltype(par_c)::value;  // 0 none, 1 bias, 2 bias + post-BatchNorm + ReLU, 3 decide at run time
@@ -399,6 +454,22 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                     for (int n = 0; n < NT; ++n) resv[r][n] = p[pix[n]];
                 }
             }
+            // the second residual (conv7: r3 + ll1 + conv7(...)) the same way - one load per output element inside the store
+            // loop is a chain of memory latencies
+            constexpr bool RES2 = GEN && PAR == 3;
+            float resv2[RES2 ? 16 : 1][NT];
+            const bool res2 = RES2 && a.res2 != nullptr;
+            if constexpr (RES2) {
+                if (res2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = cob + (r & 3) + 8 * (r >> 2);
+                        const float* const p = a.res2 + (size_t(b0) * a.res2_ctot + a.res2_coff + (co < a.cout ? co : 0)) * HW;
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) resv2[r][n] = p[pix[n]];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cob + (r & 3) + 8 * (r >> 2);
@@ -412,11 +483,14 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
+                    if constexpr (NS == 2) finite_chk = fmaf(acc[m][n][r], 0.f, finite_chk);  // stays 0 unless inf / NaN
                     float v = (NS == 2 ? acc[m][n][r] * a.fast_unscale : acc[m][n][r]) + bias;  // f16x2: weights carry a power-of-two scale
                     if (post) v = fmaxf(fmaf(v, ps, pt), 0.f);
                     if (RAW) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix[n]] = v;
                     if constexpr (RES) v += resv[r][n];
-                    if (GEN && PAR == 3 && a.res2) v += a.res2[(size_t(b0) * a.res2_ctot + a.res2_coff + co) * HW + pix[n]];
+                    if constexpr (RES2) {
+                        if (res2) v += resv2[r][n];
+                    }
                     if (!RAW || a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
                 }
             }
@@ -441,7 +515,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     else
         epilogue(F_{}, F_{}, std::integral_constant<int, 3>{});
     if constexpr (NS == 2) {
-        if (ovf && a.fast_ovf) *a.fast_ovf = 1u;  // (every writer stores the same word)
+        if (!(finite_chk == 0.f) && a.fast_ovf) *a.fast_ovf = 1u;  // (every writer stores the same word)
     }
 }
 
