@@ -136,6 +136,8 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     const void* src[4] = {verts_host, uvs_host, tris_host, with_tex ? tex_host : nullptr};
     const size_t bytes[4] = {size_t(n_verts) * 12, uvs_host ? size_t(n_verts) * 8 : 0, size_t(n_tris) * 12,
                              with_tex ? size_t(tex_h) * tex_w * 3 : 0};
+    // the rasteriser fetches a texel with one 4-byte load at byte 3 * index: 4 spare bytes behind the texture
+    const size_t room[4] = {bytes[0], bytes[1], bytes[2], bytes[3] ? bytes[3] + 4 : 0};
     size_t off[4], total = 0;
     for (int i = 0; i < 4; ++i) {
         off[i] = total;
@@ -175,7 +177,7 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
             int pick = -1;
             for (int k = 0; k < int(ctx->mesh_pool.size()); ++k) {
                 const size_t c = ctx->mesh_pool[size_t(k)].cap;
-                if (c >= bytes[i] && c <= 4 * bytes[i] + (1u << 20)) {
+                if (c >= room[i] && c <= 4 * bytes[i] + (1u << 20)) {
                     pick = k;
                     break;
                 }
@@ -189,7 +191,7 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
                 m->waited[i] = e.freed;  // returned to the event list with the mesh
                 if (e.freed && hipStreamWaitEvent(ctx->upload_stream, e.freed, 0) != hipSuccess) ok = false;
             } else {
-                m->cap[i] = (bytes[i] + 65535) / 65536 * 65536;
+                m->cap[i] = (room[i] + 65535) / 65536 * 65536;
                 if (hipMalloc(dst[i], m->cap[i]) != hipSuccess) {
                     *dst[i] = nullptr;
                     m->cap[i] = 0;
