@@ -924,16 +924,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     //   RAW: also store the pre-residual value (input of the block's next conv)
     //   RES: add the residual slice        PAR: 0 none, 1 bias, 2 bias + post-BatchNorm + ReLU
     //   POOL: also store the 2x2 max-pooled value
-    auto epilogue_fast = [&](auto raw_c, auto res_c, auto par_c, auto pool_c) __attribute__((always_inline)) {
-        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value;
+    //   RES 2: two residuals, (res1 + res2) + value (conv7: r3 + ll1 + conv7(x), paulsenpredictor.py:422)
+    //   SCAT: the hourglass up-path - the value goes to its 2x2 block of the skip tensor, added in place (:334-359)
+    auto epilogue_fast = [&](auto raw_c, auto res_c, auto par_c, auto pool_c, auto scat_c) __attribute__((always_inline)) {
+        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value != 0, RES2 = decltype(res_c)::value == 2;
         constexpr bool POOL = decltype(pool_c)::value != 0, FULL_OUT = decltype(pool_c)::value != 2;  // 2: pooled tensor only
+        constexpr bool SCAT = decltype(scat_c)::value;
         constexpr int PAR = decltype(par_c)::value;
         // residual prefetch distance in groups (measured: 3 and 5 perform alike, 6 spills on the
         // 128-accumulator tiles)
-        constexpr int PF_WANT = (GE <= 8) ? 3 : 1;
+        constexpr int PF_WANT = (GE <= 8 && !RES2 && !SCAT) ? 3 : 1;  // (two residual rings / the skip blocks: registers)
         constexpr int PF = RES ? (PF_WANT < NG ? PF_WANT : NG) : 0;
         constexpr int RING = PF + 1;
         float resv[RING][GE];
+        float resv2[RES2 ? RING : 1][GE];
         f32x4 bias_r[2], ps_r[2], pt_r[2];
         auto chan0 = [&](int g) { return co0 + (g >> 2) * 32 + 8 * (g & 3); };  // wave-uniform first channel
         auto ld_res = [&](auto gc) __attribute__((always_inline)) {
@@ -946,6 +950,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
                         constexpr int n = decltype(nc)::value;
                         resv[g % RING][j * C::NT + n] = p1[o_r1[n]];
                     });
+                    if constexpr (RES2) {
+                        const float* const p2 = a.res2 + size_t(chan0(g) + j) * HW;
+                        static_for<0, C::NT>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            resv2[g % RING][j * C::NT + n] = p2[o_r2[n]];
+                        });
+                    }
                 });
             }
         };
@@ -964,8 +975,29 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
             constexpr int m = g >> 2, rg = g & 3;
             if constexpr (g + PF < NG) ld_res(std::integral_constant<int, g + PF>{});
             if constexpr (g + 1 < NG) ld_par(std::integral_constant<int, g + 1>{});
-            __builtin_amdgcn_sched_barrier(0);  // the prefetches stay ahead of this group's work
             const int cs0 = chan0(g);
+            // the group's 2x2 blocks of the skip tensor, SK_CH channels at a time, requested before those channels' other
+            // work (two where the registers allow it: pipelining a channel ahead, or a whole group at once, spilled on the
+            // 168-register tiles)
+            constexpr int SK_CH = (C::MIN_BLOCKS_PER_CU == 2 && C::NT <= 2) ? 2 : 1;
+            float2 sk0[SCAT ? SK_CH * C::NT : 1], sk1[SCAT ? SK_CH * C::NT : 1];
+            auto ld_skip = [&](auto hc) __attribute__((always_inline)) {
+                constexpr int h = decltype(hc)::value;  // channels SK_CH h ... of the group
+                if constexpr (SCAT) {
+                    const unsigned W2 = 2u * unsigned(W);
+                    static_for<0, SK_CH>([&](auto jc) {
+                        constexpr int jj = decltype(jc)::value, j = SK_CH * h + jj;
+                        const float* const ps = a.skip + size_t(cs0 + j) * HW * 4;
+                        static_for<0, C::NT>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            sk0[jj * C::NT + n] = *reinterpret_cast<const float2*>(ps + o_skip[n]);
+                            sk1[jj * C::NT + n] = *reinterpret_cast<const float2*>(ps + o_skip[n] + W2);
+                        });
+                    });
+                }
+            };
+            if constexpr (SK_CH == 2) ld_skip(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);  // the prefetches stay ahead of this group's work
             float vals[GE];
             static_for<0, 4>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -987,7 +1019,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
                     });
                 });
             }
-            if constexpr (RES) {
+            if constexpr (RES2) {
+                static_for<0, GE>([&](auto ec) { vals[decltype(ec)::value] += resv[g % RING][decltype(ec)::value] + resv2[g % RING][decltype(ec)::value]; });
+            } else if constexpr (RES) {
                 static_for<0, GE>([&](auto ec) { vals[decltype(ec)::value] += resv[g % RING][decltype(ec)::value]; });
             }
             if constexpr (POOL && CAN_POOL) {
@@ -1003,7 +1037,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
                     });
                 });
             }
-            if constexpr (FULL_OUT) {
+            if constexpr (SCAT) {
+                const unsigned W2 = 2u * unsigned(W);
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (SK_CH == 1) ld_skip(jc);
+                    if constexpr (SK_CH == 2 && j == 2) ld_skip(std::integral_constant<int, 1>{});
+                    float* const p = a.out + size_t(cs0 + j) * HW * 4;
+                    static_for<0, C::NT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        if (lane_ok[n]) {
+                            const float v = vals[j * C::NT + n];
+                            const float2 s0 = sk0[(j % SK_CH) * C::NT + n], s1 = sk1[(j % SK_CH) * C::NT + n];
+                            *reinterpret_cast<float2*>(p + o_out[n]) = make_float2(v + s0.x, v + s0.y);
+                            *reinterpret_cast<float2*>(p + o_out[n] + W2) = make_float2(v + s1.x, v + s1.y);
+                        }
+                    });
+                });
+            } else if constexpr (FULL_OUT) {
                 static_for<0, 4>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     float* const p = a.out + size_t(cs0 + j) * HW;
@@ -1021,28 +1072,41 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     using P2 = std::integral_constant<int, 2>;
     const bool full_tile = co0 + C::COUT_T <= a.cout;
     const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr, has_pool = a.pool_out != nullptr;
-    const bool fast_ok = full_tile && !C::SPLITK && (a.out || has_pool) && !a.up_out && !a.res2 && !a.skip && (CAN_POOL || !has_pool);
+    const bool scat = a.up_out == 1 && a.skip != nullptr && a.out != nullptr;
+    const bool fast_ok = full_tile && !C::SPLITK && (a.out || has_pool) && (!a.up_out || scat) && (!a.skip || scat) && (CAN_POOL || !has_pool);
     const int par = a.post_scale ? (a.bias ? 2 : -1) : (a.bias ? 1 : 0);
     const int pool_mode = has_pool ? (a.out ? 1 : 2) : 0;
+    const int res_mode = has_res ? (a.res2 ? 2 : 1) : 0;
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
-    if (fast_ok && has_raw && has_res && par == 0 && pool_mode == 0)
-        epilogue_fast(T_{}, T_{}, P0{}, M0{});  // block conv1 / conv2
-    else if (fast_ok && !has_raw && has_res && par == 0 && pool_mode == 0)
-        epilogue_fast(F_{}, T_{}, P0{}, M0{});  // block conv3
-    else if (fast_ok && has_raw && has_res && par == 0 && pool_mode == 1)
-        epilogue_fast(T_{}, T_{}, P0{}, M1{});  // ... of a block that is pooled next
-    else if (fast_ok && !has_raw && has_res && par == 0 && pool_mode == 1)
-        epilogue_fast(F_{}, T_{}, P0{}, M1{});
-    else if (fast_ok && has_raw && has_res && par == 0 && pool_mode == 2)
-        epilogue_fast(T_{}, T_{}, P0{}, M2{});  // ... whose full-resolution output nobody reads (stem)
-    else if (fast_ok && !has_raw && has_res && par == 0 && pool_mode == 2)
-        epilogue_fast(F_{}, T_{}, P0{}, M2{});
-    else if (fast_ok && !has_raw && !has_res && par == 2 && pool_mode == 0)
-        epilogue_fast(F_{}, F_{}, P2{}, M0{});  // conv1, conv5, conv9
-    else if (fast_ok && !has_raw && !has_res && par == 0 && pool_mode == 0)
-        epilogue_fast(F_{}, F_{}, P0{}, M0{});  // 1x1 resample
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    using P1 = std::integral_constant<int, 1>;
+    const bool plain = fast_ok && !scat;  // the layer kinds of rounds 1-3
+    if (plain && has_raw && res_mode == 1 && par == 0 && pool_mode == 0)
+        epilogue_fast(T_{}, R1{}, P0{}, M0{}, F_{});  // block conv1 / conv2
+    else if (plain && !has_raw && res_mode == 1 && par == 0 && pool_mode == 0)
+        epilogue_fast(F_{}, R1{}, P0{}, M0{}, F_{});  // block conv3
+    else if (plain && has_raw && res_mode == 1 && par == 0 && pool_mode == 1)
+        epilogue_fast(T_{}, R1{}, P0{}, M1{}, F_{});  // ... of a block that is pooled next
+    else if (plain && !has_raw && res_mode == 1 && par == 0 && pool_mode == 1)
+        epilogue_fast(F_{}, R1{}, P0{}, M1{}, F_{});
+    else if (plain && has_raw && res_mode == 1 && par == 0 && pool_mode == 2)
+        epilogue_fast(T_{}, R1{}, P0{}, M2{}, F_{});  // ... whose full-resolution output nobody reads (stem)
+    else if (plain && !has_raw && res_mode == 1 && par == 0 && pool_mode == 2)
+        epilogue_fast(F_{}, R1{}, P0{}, M2{}, F_{});
+    else if (plain && !has_raw && res_mode == 0 && par == 2 && pool_mode == 0)
+        epilogue_fast(F_{}, R0{}, P2{}, M0{}, F_{});  // conv1, conv5, conv9
+    else if (plain && !has_raw && res_mode == 0 && par == 0 && pool_mode == 0)
+        epilogue_fast(F_{}, R0{}, P0{}, M0{}, F_{});  // 1x1 resample
+    else if (plain && !has_raw && res_mode == 2 && par == 1 && pool_mode == 1)
+        epilogue_fast(F_{}, R2{}, P1{}, M1{}, F_{});  // conv7 (+ the pooled copy the second hourglass starts from)
+    else if (fast_ok && scat && has_raw && res_mode == 1 && par == 0 && pool_mode == 0)
+        epilogue_fast(T_{}, R1{}, P0{}, M0{}, T_{});  // conv1 / conv2 of a level's last block on the way up
+    else if (fast_ok && scat && !has_raw && res_mode == 1 && par == 0 && pool_mode == 0)
+        epilogue_fast(F_{}, R1{}, P0{}, M0{}, T_{});  // ... its conv3
     else if (full_tile)
         epilogue(std::true_type{});
     else
