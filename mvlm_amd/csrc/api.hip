@@ -396,7 +396,7 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
         a.cout_pad = (cout + 63) / 64 * 64;
         const size_t n16 = size_t(a.cin_pad / 16) * 9 * 2 * splits * a.cout_pad * 8;
         wq = static_cast<unsigned short*>(ctx->get_scratch("conv_bench.wq", n16 * 2));
-        if (!wq || !mvlm_conv_fast_ok(a)) {
+        if (!wq || !mvlm_conv_fast_ok(a, splits)) {
             ctx->conv_force_variant = saved;
             return ctx->fail("conv_bench: shape not eligible for the fast kernel");
         }

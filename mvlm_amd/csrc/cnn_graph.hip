@@ -178,7 +178,7 @@ struct Exec {
     }
     bool runs_fast(int slot, const ConvArgs& a) const {
         const std::vector<long long>& off = st.fast == 2 ? st.fast16_off : st.fast_off;
-        return st.fast && size_t(slot) < off.size() && off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a);
+        return st.fast && size_t(slot) < off.size() && off[size_t(slot)] >= 0 && mvlm_conv_fast_ok(a, st.fast == 2 ? 2 : 3);
     }
     // per-launch HIP events (profiling runs only)
     int prof_begin(hipEvent_t& e0, hipEvent_t& e1) {

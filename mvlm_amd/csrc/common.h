@@ -305,7 +305,7 @@ inline int mvlm_fast_cout_pad(int cout) { return (cout + 63) / 64 * 64; }
 inline bool mvlm_fast_channels_ok(int cin, int cout) {
     return cin >= 16 && cin <= 256 && cout > 0 && cout * 8 >= mvlm_fast_cout_pad(cout) * 5;
 }
-bool mvlm_conv_fast_ok(const ConvArgs& a);
+bool mvlm_conv_fast_ok(const ConvArgs& a, int splits);  // splits: 3 = bf16x3 ("fast"), 2 = f16x2 ("fast16")
 int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev, int splits = 3, float unscale = 1.f);
 constexpr int MVLM_CONV_VARIANT_FAST = 62;    // id reported for launches of the bf16x3 kernel
 constexpr int MVLM_CONV_VARIANT_FAST16 = 61;  // ... of the f16x2 kernel

@@ -435,8 +435,10 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     // NaN), so the kernel raises the context's flag word; the executor turns the pass's maxima into NaN when it is set
     // (cnn_graph.hip) and the caller repeats the pass on bf16x3.
     float finite_chk = 0.f;
-    auto epilogue = [&](auto raw_c, auto res_c, auto par_c) __attribute__((always_inline)) {
-        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value;
+    // SCAT: the hourglass up-path (paulsenpredictor.py:334-359) - the value goes to its 2x2 block of the skip tensor,
+    // added in place; the blocks of four channels are requested together before those channels are finished
+    auto epilogue = [&](auto raw_c, auto res_c, auto par_c, auto scat_c) __attribute__((always_inline)) {
+        constexpr bool RAW = decltype(raw_c)::value, RES = decltype(res_c)::value, SCAT = decltype(scat_c)::value;
         constexpr int PAR = decltype(par_c)::value;  // 0 none, 1 bias, 2 bias + post-BatchNorm + ReLU, 3 decide at run time
         static_for<0, MT>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -470,50 +472,86 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                     }
                 }
             }
+            unsigned pix2[SCAT ? NT : 1];  // first element of the pixel's 2x2 block in the full-resolution plane
+            if constexpr (SCAT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cob + (r & 3) + 8 * (r >> 2);
-                if (co >= a.cout) continue;
-                float bias = 0.f, ps = 1.f, pt = 0.f;
-                if (PAR == 1 || PAR == 2 || (PAR == 3 && a.bias)) bias = a.bias[co];
-                const bool post = PAR == 2 || (PAR == 3 && a.post_scale);
-                if (post) {
-                    ps = a.post_scale[co];
-                    pt = a.post_shift[co];
-                }
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    if constexpr (NS == 2) finite_chk = fmaf(acc[m][n][r], 0.f, finite_chk);  // stays 0 unless inf / NaN
-                    float v = (NS == 2 ? acc[m][n][r] * a.fast_unscale : acc[m][n][r]) + bias;  // f16x2: weights carry a power-of-two scale
-                    if (post) v = fmaxf(fmaf(v, ps, pt), 0.f);
-                    if (RAW) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix[n]] = v;
-                    if constexpr (RES) v += resv[r][n];
-                    if constexpr (RES2) {
-                        if (res2) v += resv2[r][n];
-                    }
-                    if (!RAW || a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
-                }
+                for (int n = 0; n < NT; ++n) pix2[n] = unsigned(2 * (y0 + NT * wn + n)) * unsigned(2 * W) + unsigned(2 * (x0 + l31));
             }
+            const unsigned W2 = 2u * unsigned(W);
+            constexpr int SKB = NT <= 2 ? 4 : 2;  // channels whose skip blocks are in flight together (64 x 16 tile: registers)
+            static_for<0, 16 / SKB>([&](auto rbc) {
+                constexpr int rb = decltype(rbc)::value;  // accumulator registers SKB rb ... (register r = channel cob + (r & 3) + 8 (r >> 2))
+                f32x2 sk0[SCAT ? SKB : 1][NT], sk1[SCAT ? SKB : 1][NT];
+                if constexpr (SCAT) {
+#pragma unroll
+                    for (int q = 0; q < SKB; ++q) {
+                        const int r = SKB * rb + q;
+                        const int co = cob + (r & 3) + 8 * (r >> 2);
+                        const float* const ps = a.skip + (size_t(b0) * a.skip_ctot + a.skip_coff + (co < a.cout ? co : 0)) * (4 * size_t(HW));
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            sk0[q][n] = *reinterpret_cast<const f32x2*>(ps + pix2[n]);
+                            sk1[q][n] = *reinterpret_cast<const f32x2*>(ps + pix2[n] + W2);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SKB; ++q) {
+                    const int r = SKB * rb + q;
+                    const int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (co >= a.cout) continue;
+                    float bias = 0.f, ps = 1.f, pt = 0.f;
+                    if (PAR == 1 || PAR == 2 || (PAR == 3 && a.bias)) bias = a.bias[co];
+                    const bool post = PAR == 2 || (PAR == 3 && a.post_scale);
+                    if (post) {
+                        ps = a.post_scale[co];
+                        pt = a.post_shift[co];
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if constexpr (NS == 2) finite_chk = fmaf(acc[m][n][r], 0.f, finite_chk);  // stays 0 unless inf / NaN
+                        float v = (NS == 2 ? acc[m][n][r] * a.fast_unscale : acc[m][n][r]) + bias;  // f16x2: weights carry a power-of-two scale
+                        if (post) v = fmaxf(fmaf(v, ps, pt), 0.f);
+                        if (RAW) a.out_raw[(size_t(b0) * a.raw_ctot + a.raw_coff + co) * HW + pix[n]] = v;
+                        if constexpr (RES) v += resv[r][n];
+                        if constexpr (RES2) {
+                            if (res2) v += resv2[r][n];
+                        }
+                        if constexpr (SCAT) {
+                            float* const po = a.out + (size_t(b0) * a.out_ctot + a.out_coff + co) * (4 * size_t(HW)) + pix2[n];
+                            *reinterpret_cast<f32x2*>(po) = (f32x2){v + sk0[q][n].x, v + sk0[q][n].y};
+                            *reinterpret_cast<f32x2*>(po + W2) = (f32x2){v + sk1[q][n].x, v + sk1[q][n].y};
+                        } else {
+                            if (!RAW || a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
+                        }
+                    }
+                }
+            });
         });
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
     const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr;
     const bool plain = !a.bias && !a.post_scale && !a.res2;
-    if (has_raw && has_res && plain && a.out)
-        epilogue(T_{}, T_{}, std::integral_constant<int, 0>{});   // residual block conv1 / conv2
+    const bool scat = a.up_out == 1;
+    if (scat && has_raw)
+        epilogue(T_{}, T_{}, std::integral_constant<int, 0>{}, T_{});   // conv1 / conv2 of a level's last block on the way up
+    else if (scat)
+        epilogue(F_{}, T_{}, std::integral_constant<int, 0>{}, T_{});   // ... its conv3
+    else if (has_raw && has_res && plain && a.out)
+        epilogue(T_{}, T_{}, std::integral_constant<int, 0>{}, F_{});   // residual block conv1 / conv2
     else if (!has_raw && has_res && plain)
-        epilogue(F_{}, T_{}, std::integral_constant<int, 0>{});   // residual block conv3
+        epilogue(F_{}, T_{}, std::integral_constant<int, 0>{}, F_{});   // residual block conv3
     else if (!has_raw && !has_res && a.bias && a.post_scale && !a.res2)
-        epilogue(F_{}, F_{}, std::integral_constant<int, 2>{});   // conv5 / conv9
+        epilogue(F_{}, F_{}, std::integral_constant<int, 2>{}, F_{});   // conv5 / conv9
     else if (has_raw && has_res)
-        epilogue(T_{}, T_{}, std::integral_constant<int, 3>{});
+        epilogue(T_{}, T_{}, std::integral_constant<int, 3>{}, F_{});
     else if (has_raw)
-        epilogue(T_{}, F_{}, std::integral_constant<int, 3>{});
+        epilogue(T_{}, F_{}, std::integral_constant<int, 3>{}, F_{});
     else if (has_res)
-        epilogue(F_{}, T_{}, std::integral_constant<int, 3>{});
+        epilogue(F_{}, T_{}, std::integral_constant<int, 3>{}, F_{});
     else
-        epilogue(F_{}, F_{}, std::integral_constant<int, 3>{});
+        epilogue(F_{}, F_{}, std::integral_constant<int, 3>{}, F_{});
     if constexpr (NS == 2) {
         if (!(finite_chk == 0.f) && a.fast_ovf) *a.fast_ovf = 1u;  // (every writer stores the same word)
     }
@@ -547,16 +585,21 @@ int launch_fast_ns(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_de
 }  // namespace
 
 // can the fast kernel serve this launch?  (its own paddings: mvlm_fast_cin_pad / mvlm_fast_cout_pad, common.h)
-bool mvlm_conv_fast_ok(const ConvArgs& a) {
+bool mvlm_conv_fast_ok(const ConvArgs& a, int splits) {
     if (a.ksize != 3 || !mvlm_fast_channels_ok(a.cin, a.cout)) return false;
     // 128-channel tiles cover 8 rows, 64-channel tiles 16 rows (same matrix work per staged input tile)
     const int rows = mvlm_fast_cout_pad(a.cout) % 128 == 0 ? 8 : 16;
-    return a.W % FT_TW == 0 && a.H % rows == 0 && !a.up_in && !a.up_out && !a.skip && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
+    // plain NCHW output, or the up-path form: 2x2 scatter into the skip tensor (a residual block's layer: one residual, no
+    // bias).  The f16x2 form only: its K loop is short enough for the unoverlapped scatter to pay (rb20.conv1 2089 -> 785 us,
+    // the step 59.2 -> 55.0 ms); on bf16x3 the same twelve launches bought 3 % and their different rounding flipped one of
+    // 8 064 near-tied argmax planes of the bench's random-weight network, so that form keeps round 2's layer set
+    const bool scatter = splits == 2 && a.up_out == 1 && a.skip && a.out && a.res1 && !a.res2 && !a.bias && !a.post_scale;
+    return a.W % FT_TW == 0 && a.H % rows == 0 && !a.up_in && ((!a.up_out && !a.skip) || scatter) && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
 }
 
 // splits: 3 = bf16x3 ("fast"), 2 = f16x2 ("fast16": the weights carry the power-of-two scale 1 / unscale)
 int mvlm_launch_conv_fast(mvlm_ctx* ctx, const ConvArgs& exact, const unsigned short* wq_dev, int splits, float unscale) {
-    MVLM_REQUIRE(ctx, mvlm_conv_fast_ok(exact) && wq_dev && (splits == 3 || splits == 2), "conv_fast: launch not eligible");
+    MVLM_REQUIRE(ctx, (splits == 3 || splits == 2) && mvlm_conv_fast_ok(exact, splits) && wq_dev, "conv_fast: launch not eligible");
     ConvArgs a = exact;  // the split weights carry their own paddings
     a.fast_ovf = splits == 2 ? ctx->cnn.fast16_flag : nullptr;
     a.cin_pad = mvlm_fast_cin_pad(a.cin);

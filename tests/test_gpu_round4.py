@@ -482,6 +482,42 @@ def test_fast16_network_close_to_exact(family):
     assert pred.fast16_fallbacks == 0
 
 
+def test_fast16_serves_the_up_path_blocks():
+    """The last block of a hourglass level on the way up (2x2 scatter into the skip tensor, paulsenpredictor.py:334-359) runs
+    on the split kernel in the f16x2 form only: its slots report the split variant under "fast16", an exact tile under
+    "fast" (conv_fast.hip: mvlm_conv_fast_ok)."""
+    from mvlm_amd import arch
+    from mvlm_amd.prediction import DTU3DPredictor
+
+    pred = DTU3DPredictor(image_mode="RGB", weights="synthetic:4", verbose=False)
+    imgs = dev(seeded_images(43, 4))
+    lib, h = pred.ctx.lib, pred.ctx.handle
+    names = [sl.name for sl in arch.conv_slots(73, 3)]
+    cap = 1024
+    slot, var = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    fl, ms = (C.c_double * cap)(), (C.c_float * cap)()
+
+    def variants(precision):
+        pred.set_precision(precision)
+        pred.predict_device(imgs)
+        lib.mvlm_cnn_set_profiling(h, 1)
+        pred.predict_device(imgs)
+        torch.cuda.synchronize()
+        n = lib.mvlm_cnn_get_profile(h, slot, var, fl, ms, cap)
+        lib.mvlm_cnn_set_profiling(h, 0)
+        assert n > 0
+        return {names[slot[i]]: lib.mvlm_conv_variant_name(var[i]).decode() for i in range(n) if slot[i] >= 0}
+
+    try:
+        v16, v3 = variants("fast16"), variants("fast")
+    finally:
+        pred.set_precision("exact")
+    up = [f"hg{g}.rb{b}.conv{c}" for g in (1, 2) for b in (18, 20) for c in (1, 2, 3)]  # the 32x32 and 64x64 levels' last blocks
+    assert all("f16x2" in v16[k] for k in up), {k: v16[k] for k in up}
+    assert not any("bf16x3" in v3[k] for k in up), {k: v3[k] for k in up}
+    assert "f16x2" in v16["hg1.rb19.conv1"] and "bf16x3" in v3["hg1.rb19.conv1"]  # the plain blocks: both forms
+
+
 @pytest.mark.parametrize("name,mode,n_views", [("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)])
 def test_fast16_against_the_oracle(name, mode, n_views):
     """precision="fast16" against the CPU ORACLE (never the default, never bench.py's value): the same render, at most
