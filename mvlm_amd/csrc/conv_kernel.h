@@ -1101,12 +1101,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
         epilogue_fast(F_{}, R0{}, P2{}, M0{}, F_{});  // conv1, conv5, conv9
     else if (plain && !has_raw && res_mode == 0 && par == 0 && pool_mode == 0)
         epilogue_fast(F_{}, R0{}, P0{}, M0{}, F_{});  // 1x1 resample
-    else if (plain && !has_raw && res_mode == 2 && par == 1 && pool_mode == 1)
-        epilogue_fast(F_{}, R2{}, P1{}, M1{}, F_{});  // conv7 (+ the pooled copy the second hourglass starts from)
-    else if (fast_ok && scat && has_raw && res_mode == 1 && par == 0 && pool_mode == 0)
-        epilogue_fast(T_{}, R1{}, P0{}, M0{}, T_{});  // conv1 / conv2 of a level's last block on the way up
-    else if (fast_ok && scat && !has_raw && res_mode == 1 && par == 0 && pool_mode == 0)
-        epilogue_fast(F_{}, R1{}, P0{}, M0{}, T_{});  // ... its conv3
+    // (the two kinds below only where such a layer can run - 3x3 tiles without a strip: every kind compiled into a tile
+    //  costs it registers, and the 80-row tile fell from three resident workgroups per CU to two with them: 166 -> 191)
+    else if (C::KS == 3 && !C::TAIL16 && plain && !has_raw && res_mode == 2 && par == 1 && pool_mode == 1) {
+        if constexpr (C::KS == 3 && !C::TAIL16) epilogue_fast(F_{}, R2{}, P1{}, M1{}, F_{});  // conv7 (+ the pooled copy the second hourglass starts from)
+    } else if (C::KS == 3 && !C::TAIL16 && fast_ok && scat && has_raw && res_mode == 1 && par == 0 && pool_mode == 0) {
+        if constexpr (C::KS == 3 && !C::TAIL16) epilogue_fast(T_{}, R1{}, P0{}, M0{}, T_{});  // conv1 / conv2 of a level's last block on the way up
+    } else if (C::KS == 3 && !C::TAIL16 && fast_ok && scat && !has_raw && res_mode == 1 && par == 0 && pool_mode == 0) {
+        if constexpr (C::KS == 3 && !C::TAIL16) epilogue_fast(F_{}, R1{}, P0{}, M0{}, T_{});  // ... its conv3
+    }
     else if (full_tile)
         epilogue(std::true_type{});
     else
