@@ -25,6 +25,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.mvlm_build_arch() == b"gfx950"
 
 
+def test_kernel_occupancy_table():
+    """Every kernel of the built objects holds at least the waves per SIMD and spills at most the registers that
+    tests/golden/kernel_occupancy.json records (tools/kernel_occupancy.py --write after a deliberate change): a tile that
+    silently crosses a register boundary loses a resident workgroup per CU - a third of its rate at small batches."""
+    import importlib.util
+
+    build = REPO / "mvlm_amd" / "csrc" / "build"
+    if not any(build.glob("*.o")):
+        pytest.skip("no object files (the library was not built from source here)")
+    spec = importlib.util.spec_from_file_location("kernel_occupancy", REPO / "tools" / "kernel_occupancy.py")
+    ko = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ko)
+    assert ko.waves_per_simd(166) == 3 and ko.waves_per_simd(191) == 2 and ko.waves_per_simd(64) == 8 and ko.waves_per_simd(256) == 2
+    want = json.loads(ko.TABLE.read_text())
+    got = ko.build_table()
+    assert len(got) >= 80  # conv variants (single + pair), split kernels, rasteriser, fusion, surface, misc
+    worse = {k: (want[k], {f: v[f] for f in ("waves_per_simd", "spilled", "vgprs")}) for k, v in got.items()
+             if k in want and (v["waves_per_simd"] < want[k]["waves_per_simd"] or v["spilled"] > want[k]["spilled"])}
+    assert not worse, worse
+    unknown = sorted(set(got) - set(want))
+    assert not unknown, f"kernels missing from the table (tools/kernel_occupancy.py --write): {unknown[:5]}"
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
