@@ -22,6 +22,6 @@ for (b, cin, cout, size, flags) in ((96, 256, 128, 128, 3), (96, 256, 256, 128, 
         ms, used = C.c_float(), C.c_int()
         rc = lib.mvlm_conv_bench(ctx.handle, b, cin, cout, 3, size, flags, v, 6, C.byref(ms), C.byref(used))
         fl = 2.0 * cin * cout * 9 * size * size * b
-        print(f"  B{b} {cin}->{cout} @{size} variant {v:3d}: rc {rc} {ms.value * 1e3:9.1f} us  {fl / (ms.value * 1e-3) / 1e12 if rc == 0 else 0:7.1f} TF-equiv")
+        print(f"  B{b} {cin}->{cout} @{size} variant {v:3d}: rc {rc} {ms.value * 1e3:9.1f} us  {fl / (ms.value * 1e-3) / 1e12 if rc == 0 else 0:7.1f} TF-equiv", flush=True)
 PY
 done
