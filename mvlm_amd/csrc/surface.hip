@@ -1,8 +1,11 @@
-// Snap landmarks to the closest point of the triangle surface: every (landmark, triangle) pair is
-// tested exactly in float64 (two passes: per-chunk winners, then the winner), replacing the reference's
+// Snap landmarks to the closest point of the triangle surface: the result of testing every (landmark, triangle) pair
+// exactly in float64 (an upper bound per landmark, per-chunk winners among the triangles the bound cannot exclude, then
+// the winner), replacing the reference's
 // vtkCleanPolyData + vtkCellLocator.FindClosestPoint loop
 // (src/mvlm/utils/estimator3d.py:252-285).  100k triangles x 84 landmarks is 8.4 M
 // point-triangle tests - far cheaper on the GPU than building a locator.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -36,57 +39,164 @@ __device__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
     return {a.x + ab.x * v + ac.x * w, a.y + ab.y * v + ac.y * w, a.z + ab.z * v + ac.z * w};
 }
 
-// Pass 1: one workgroup per (landmark, chunk of PROJECT_CHUNK triangles) -> the chunk's nearest
-// triangle (squared distance, id).  73-84 landmarks alone would leave 2/3 of the chip idle
-// (one workgroup per landmark: 310 us on 73 workgroups); chunking gives ~50x more workgroups.
-constexpr int PROJECT_CHUNK = 2048;
-
-__global__ __launch_bounds__(256) void project_partial_kernel(const float* __restrict__ verts,
-                                                              const int32_t* __restrict__ tris, int n_tris,
-                                                              const double* __restrict__ pts, int n_chunks,
-                                                              double* __restrict__ part_d, int* __restrict__ part_t) {
-    const int lm = blockIdx.y, chunk = blockIdx.x;
+// Pass 0: an upper bound on every landmark's squared distance to the surface - its distance to the nearest VERTEX (a
+// vertex is a point of the surface).  BOUND_SPLIT workgroups per landmark stride over the vertices (0.6 MB, L2-resident),
+// four loads in flight per thread; the minimum goes to ub[] with an atomic min on the bit pattern (non-negative doubles
+// order like their bits).  ub[] starts at 0x7f7f... = 1.4e306, "no bound": it stays there for a non-finite landmark,
+// whose comparisons are all false.
+constexpr int BOUND_SPLIT = 8;
+__global__ __launch_bounds__(256) void project_bound_kernel(const float* __restrict__ verts, int n_verts,
+                                                            const double* __restrict__ pts, unsigned long long* __restrict__ ub) {
+    const int lm = blockIdx.x;
     const V3 p = {pts[lm * 3], pts[lm * 3 + 1], pts[lm * 3 + 2]};
     double best = INFINITY;
-    int best_t = 0x7fffffff;
-    const int t_end = min(n_tris, (chunk + 1) * PROJECT_CHUNK);
-    for (int t = chunk * PROJECT_CHUNK + threadIdx.x; t < t_end; t += blockDim.x) {
-        const int ia = tris[3 * t], ib = tris[3 * t + 1], ic = tris[3 * t + 2];
-        const V3 a = {verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]};
-        const V3 b = {verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]};
-        const V3 c = {verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]};
-        const V3 q = closest_on_triangle(p, a, b, c);
-        const V3 d = sub(q, p);
-        const double d2 = dot(d, d);
-        if (d2 < best) {  // strided ascending t: first minimum per thread
-            best = d2;
-            best_t = t;
+    const int stride = BOUND_SPLIT * 256;
+    for (int v0 = blockIdx.y * 256 + threadIdx.x; v0 < n_verts; v0 += 4 * stride) {
+        V3 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = min(v0 + k * stride, n_verts - 1);  // (a repeated vertex changes no minimum)
+            q[k] = V3{verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const V3 d = sub(q[k], p);
+            const double d2 = dot(d, d);
+            best = d2 < best ? d2 : best;  // (NaN never wins)
         }
     }
-    // (distance, id) minimum over the workgroup: lowest triangle id on ties
     for (int s = 32; s >= 1; s >>= 1) {
-        const double od = __shfl_down(best, s);
-        const int ot = __shfl_down(best_t, s);
-        if (od < best || (od == best && ot < best_t)) {
-            best = od;
-            best_t = ot;
+        const double o = __shfl_down(best, s);
+        best = o < best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best < INFINITY) atomicMin(&ub[lm], (unsigned long long)__double_as_longlong(best));
+}
+
+// The triangles once more, de-indexed and component-major: soup[e * n_tris + t], e = 0..8 = a.xyz, b.xyz, c.xyz.
+// Pass 1 reads every triangle once per GROUP of landmarks (60 times for 478 landmarks); through the index list that is
+// four scattered loads per triangle and group, and the L1s' rate for scattered lines - not the arithmetic - set its
+// time (7 us per 1 024 triangles and CU).  One gather pass per call (3.6 MB for 99 458 triangles) makes all of them
+// coalesced streams.
+__global__ __launch_bounds__(256) void project_soup_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tris,
+                                                           int n_tris, float* __restrict__ soup) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tris) return;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int i = tris[3 * t + e];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) soup[size_t(3 * e + d) * n_tris + t] = verts[3 * i + d];
+    }
+}
+
+// Pass 1: one workgroup per (chunk of PROJECT_CHUNK triangles, group of PROJECT_GROUP landmarks) -> per landmark the
+// chunk's nearest triangle (squared distance, id).  A thread reads a triangle ONCE and tests it against the group's
+// landmarks (rounds 1-3: one workgroup per landmark and chunk, every pair paid its own four gathers and the full
+// Voronoi walk: 135 us for 478 landmarks x 99 458 triangles, at the rate of the L1s and of the f64 pipe at once).
+// Most pairs end at a sphere test: every point of triangle (a, b, c) lies within R = max(|ab|, |ac|) of a, so its
+// distance to p is at least |pa| - R; with the landmark's upper bound u2 (pass 0) the triangle can be neither the
+// winner nor tied with it once |pa| > u + R, which |pa|^2 > 2 (u2 + R^2) implies (2 u R <= u2 + R^2): no root.  The
+// comparison carries a relative margin of 1e-12 (the exact walk's own rounding is of the order 1e-16), so the result
+// is what the walk over ALL triangles gives, ties (lowest id) included.  The landmarks' coordinates and bounds are
+// wave-uniform: they are read through scalar loads and stay in scalar registers (an LDS copy cost a read latency per
+// pair: 100 us for the pass).
+constexpr int PROJECT_CHUNK = 1024;
+constexpr int PROJECT_GROUP = 8;
+
+__global__ __launch_bounds__(256) void project_partial_kernel(const float* __restrict__ soup, int n_tris,
+                                                              const double* __restrict__ pts, int n_points,
+                                                              const unsigned long long* __restrict__ ub, int n_chunks,
+                                                              int n_sub, double* __restrict__ part_d, int* __restrict__ part_t) {
+    __shared__ double s_d[PROJECT_GROUP][4];
+    __shared__ int s_t[PROJECT_GROUP][4];
+    const int chunk = blockIdx.x, lm0 = blockIdx.y * PROJECT_GROUP;
+    const int n_lm = min(PROJECT_GROUP, n_points - lm0);
+    double px[PROJECT_GROUP], py[PROJECT_GROUP], pz[PROJECT_GROUP], u2[PROJECT_GROUP];  // (uniform: scalar registers)
+#pragma unroll
+    for (int g = 0; g < PROJECT_GROUP; ++g) {
+        const int lm = lm0 + min(g, n_lm - 1);
+        px[g] = pts[lm * 3];
+        py[g] = pts[lm * 3 + 1];
+        pz[g] = pts[lm * 3 + 2];
+        u2[g] = __longlong_as_double((long long)ub[lm]);  // ("no bound" = 1.4e306 never skips; nor do NaN / inf landmarks)
+    }
+    double best[PROJECT_GROUP];
+    int best_t[PROJECT_GROUP];
+#pragma unroll
+    for (int g = 0; g < PROJECT_GROUP; ++g) {
+        best[g] = INFINITY;
+        best_t[g] = 0x7fffffff;
+    }
+    // A workgroup walks n_sub pieces of PROJECT_CHUNK triangles (the host picks n_sub so that the grid still fills the chip:
+    // the eight reductions at the end are then paid once per several thousand triangles); a thread's TPT triangles of a
+    // piece are TPT x 9 coalesced loads in flight together.
+    constexpr int TPT = PROJECT_CHUNK / 256;
+    for (int sc = 0; sc < n_sub; ++sc) {
+        const int t0 = (chunk * n_sub + sc) * PROJECT_CHUNK;
+        if (t0 >= n_tris) break;  // (uniform)
+        float xyz[TPT][9];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int t = min(t0 + k * 256 + int(threadIdx.x), n_tris - 1);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) xyz[k][e] = soup[size_t(e) * n_tris + t];
+        }
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int t = t0 + k * 256 + int(threadIdx.x);
+            if (t >= n_tris) break;
+            const V3 a = {xyz[k][0], xyz[k][1], xyz[k][2]};
+            const V3 b = {xyz[k][3], xyz[k][4], xyz[k][5]};
+            const V3 c = {xyz[k][6], xyz[k][7], xyz[k][8]};
+            const V3 ab = sub(b, a), ac = sub(c, a);
+            const double r2ab = dot(ab, ab), r2ac = dot(ac, ac);
+            const double R2 = r2ab > r2ac ? r2ab : r2ac;
+#pragma unroll
+            for (int g = 0; g < PROJECT_GROUP; ++g) {
+                const V3 p = {px[g], py[g], pz[g]};
+                const V3 pa = sub(a, p);
+                if (dot(pa, pa) > (u2[g] + R2) * (2.0 * (1.0 + 1e-12))) continue;  // farther than the bound allows (false for NaN / inf)
+                const V3 q = closest_on_triangle(p, a, b, c);
+                const V3 d = sub(q, p);
+                const double d2 = dot(d, d);
+                if (d2 < best[g]) {  // ascending t per thread: first minimum
+                    best[g] = d2;
+                    best_t[g] = t;
+                }
+            }
         }
     }
-    __shared__ double s_d[4];
-    __shared__ int s_t[4];
-    if ((threadIdx.x & 63) == 0) {
-        s_d[threadIdx.x >> 6] = best;
-        s_t[threadIdx.x >> 6] = best_t;
+    // (distance, id) minimum over the workgroup, per landmark: lowest triangle id on ties
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < PROJECT_GROUP; ++g) {
+        double bd = best[g];
+        int bt = best_t[g];
+        for (int s = 32; s >= 1; s >>= 1) {
+            const double od = __shfl_down(bd, s);
+            const int ot = __shfl_down(bt, s);
+            if (od < bd || (od == bd && ot < bt)) {
+                bd = od;
+                bt = ot;
+            }
+        }
+        if (lane == 0) {
+            s_d[g][wave] = bd;
+            s_t[g][wave] = bt;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (int(threadIdx.x) < n_lm) {
+        const int g = threadIdx.x;
+        double bd = s_d[g][0];
+        int bt = s_t[g][0];
         for (int w = 1; w < 4; ++w)
-            if (s_d[w] < best || (s_d[w] == best && s_t[w] < best_t)) {
-                best = s_d[w];
-                best_t = s_t[w];
+            if (s_d[g][w] < bd || (s_d[g][w] == bd && s_t[g][w] < bt)) {
+                bd = s_d[g][w];
+                bt = s_t[g][w];
             }
-        part_d[size_t(lm) * n_chunks + chunk] = best;
-        part_t[size_t(lm) * n_chunks + chunk] = best_t;
+        part_d[size_t(lm0 + g) * n_chunks + chunk] = bd;
+        part_t[size_t(lm0 + g) * n_chunks + chunk] = bt;
     }
 }
 
@@ -249,13 +359,22 @@ extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, con
     MVLM_REQUIRE(ctx, mesh && pts_dev && out_dev && n_points > 0, "project_to_surface: bad arguments");
     MVLM_REQUIRE(ctx, mesh->n_tris > 0, "project_to_surface: empty mesh");
     if (mvlm_mesh_wait_ready(ctx, mesh, ctx->stream)) return 1;
-    const int n_chunks = (mesh->n_tris + PROJECT_CHUNK - 1) / PROJECT_CHUNK;
+    // pieces of PROJECT_CHUNK triangles, n_sub of them per workgroup: as many as leave >= ~768 workgroups (3 per CU)
+    const int n_pieces = (mesh->n_tris + PROJECT_CHUNK - 1) / PROJECT_CHUNK, n_groups = (n_points + PROJECT_GROUP - 1) / PROJECT_GROUP;
+    const int n_sub = std::max(1, std::min(8, int(long(n_pieces) * n_groups / 768)));
+    const int n_chunks = (n_pieces + n_sub - 1) / n_sub;
     auto* part_d = static_cast<double*>(ctx->get_scratch("project.part_d", size_t(n_points) * n_chunks * sizeof(double)));
     auto* part_t = static_cast<int*>(ctx->get_scratch("project.part_t", size_t(n_points) * n_chunks * sizeof(int)));
-    MVLM_REQUIRE(ctx, part_d && part_t, "project_to_surface: scratch allocation failed");
+    auto* ub = static_cast<unsigned long long*>(ctx->get_scratch("project.ub", size_t(n_points) * sizeof(unsigned long long)));
+    auto* soup = static_cast<float*>(ctx->get_scratch("project.soup", size_t(9) * mesh->n_tris * sizeof(float)));
+    MVLM_REQUIRE(ctx, part_d && part_t && ub && soup, "project_to_surface: scratch allocation failed");
     MVLM_REQUIRE(ctx, n_points <= 65535, "project_to_surface: at most 65535 points per call");
-    hipLaunchKernelGGL(project_partial_kernel, dim3(n_chunks, n_points), dim3(256), 0, ctx->stream, mesh->verts,
-                       mesh->tris, mesh->n_tris, pts_dev, n_chunks, part_d, part_t);
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(ub, 0x7f, size_t(n_points) * sizeof(unsigned long long), ctx->stream));  // 1.4e306: "no bound yet"
+    hipLaunchKernelGGL(project_bound_kernel, dim3(n_points, BOUND_SPLIT), dim3(256), 0, ctx->stream, mesh->verts, mesh->n_verts, pts_dev, ub);
+    hipLaunchKernelGGL(project_soup_kernel, dim3((mesh->n_tris + 255) / 256), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris,
+                       mesh->n_tris, soup);
+    hipLaunchKernelGGL(project_partial_kernel, dim3(n_chunks, n_groups), dim3(256), 0, ctx->stream, soup, mesh->n_tris, pts_dev,
+                       n_points, ub, n_chunks, n_sub, part_d, part_t);
     hipLaunchKernelGGL(project_final_kernel, dim3(n_points), dim3(64), 0, ctx->stream, mesh->verts, mesh->tris, pts_dev,
                        n_chunks, part_d, part_t, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());

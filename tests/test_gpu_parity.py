@@ -212,6 +212,33 @@ def test_project_to_surface_matches_oracle():
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("grid,n_points", [(60, 500), (224, 70), (3, 33)])
+def test_project_to_surface_bound_never_excludes_the_winner(grid, n_points):
+    """The snap tests a triangle exactly only if a sphere bound cannot exclude it (surface.hip: distance to the nearest
+    vertex as upper bound, |pa| - max edge as lower bound).  Points where that bound is tight or useless - on vertices, on
+    edge midpoints (two triangles tie), on face centres, far outside the mesh, between groups of 16 landmarks (500 = 31 x 16
+    + 4) - against the oracle's walk over all triangles."""
+    from mvlm_amd.utils import HipEstimator3D
+    from oracle import surface
+
+    m = _mesh(grid, 64, 3)
+    rs = np.random.RandomState(grid)
+    v, t = m.verts.astype(np.float64), m.tris
+    k = n_points // 5
+    tri = t[rs.randint(0, m.n_tris, k)]
+    pts = np.concatenate([
+        v[rs.randint(0, m.n_verts, k)],                                   # on vertices (distance 0, many triangles tie)
+        0.5 * (v[tri[:, 0]] + v[tri[:, 1]]),                                # on edge midpoints
+        (v[tri[:, 0]] + v[tri[:, 1]] + v[tri[:, 2]]) / 3 + rs.normal(0, 1e-3, (k, 3)),  # just off face centres
+        rs.uniform(-1000, 1000, (k, 3)),                                    # far outside: the bound excludes nothing much
+        rs.uniform(-120, 120, (n_points - 4 * k, 3)),                       # around the surface
+    ])
+    got = HipEstimator3D(verbose=False).project_landmarks_to_surface(m, pts)
+    want = surface.project_landmarks_to_surface(m.verts, m.tris, pts)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    assert np.abs(got[:k] - pts[:k]).max() < 1e-12  # a point on a vertex stays there
+
+
 # --------------------------------------------------------------------------------------
 # the whole network against vectors produced by the reference's own MVLMModel
 def _near_tie_ok(heat_plane, got_rc, want_rc, rel=2e-4):
