@@ -361,6 +361,7 @@ extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, con
     if (mvlm_mesh_wait_ready(ctx, mesh, ctx->stream)) return 1;
     // pieces of PROJECT_CHUNK triangles, n_sub of them per workgroup: as many as leave >= ~768 workgroups (3 per CU)
     const int n_pieces = (mesh->n_tris + PROJECT_CHUNK - 1) / PROJECT_CHUNK, n_groups = (n_points + PROJECT_GROUP - 1) / PROJECT_GROUP;
+    // (measured, 478 landmarks x 98 pieces: 1 / 2 / 3 / 4 / 7 pieces per workgroup = 70 / 56 / 51 / 51 / 51 us)
     const int n_sub = std::max(1, std::min(8, int(long(n_pieces) * n_groups / 768)));
     const int n_chunks = (n_pieces + n_sub - 1) / n_sub;
     auto* part_d = static_cast<double*>(ctx->get_scratch("project.part_d", size_t(n_points) * n_chunks * sizeof(double)));
