@@ -118,6 +118,30 @@ def test_render_bit_exact(grid, n_views, textured):
     assert 0.1 < cover < 0.9  # the mesh is really in view
 
 
+def test_render_samples_the_last_texel():
+    """The texel is fetched with ONE 4-byte load at byte 3 * index (raster.hip); for the last texel of the image that load
+    ends one byte behind the texture, inside the spare bytes the upload reserves (api.hip).  A 256 x 256 texture is exactly
+    three 64-KB allocation granules, so without the reserve the load would leave the buffer: every pixel of a window-filling
+    triangle samples that texel."""
+    from mvlm_amd.utils import HipRenderer3D, Mesh
+    from oracle import raster
+
+    verts = np.array([[-400, -400, 0], [400, -400, 0], [0, 600, 0]], np.float32)
+    tris = np.array([[0, 1, 2]], np.int32)
+    uvs = np.tile(np.array([[0.999, 0.001]], np.float32), (3, 1))   # -> column 255, bottom row = the last texel in memory
+    tex = np.random.RandomState(3).randint(0, 256, (256, 256, 3)).astype(np.uint8)
+    tex[-1, -1] = (11, 222, 133)
+    m = Mesh(verts, tris, uvs, tex)
+    r = HipRenderer3D(n_views=8, verbose=False)
+    poses = r.generate_3d_transformations()
+    got = r.render_device(m, poses).cpu().numpy()
+    want = raster.multiview_render(m.verts, m.tris, m.uvs, m.texture, poses)
+    np.testing.assert_array_equal(got, want)
+    hit = got[..., 3] != np.float32(1 / 255)
+    assert hit.mean() > 0.9
+    np.testing.assert_array_equal(got[hit][:, :3], np.tile(np.float32([11, 222, 133]) / np.float32(255), (int(hit.sum()), 1)))
+
+
 def test_render_degenerate_and_offscreen_triangles():
     from mvlm_amd.utils import HipRenderer3D, Mesh
     from oracle import raster
