@@ -393,7 +393,7 @@ extern "C" int mvlm_conv_bench(mvlm_ctx* ctx, int batch, int cin, int cout, int 
     const int splits = variant == MVLM_CONV_VARIANT_FAST ? 3 : (variant == MVLM_CONV_VARIANT_FAST16 ? 2 : 0);
     if (splits) {
         a.cin_pad = (cin + 15) / 16 * 16;
-        a.cout_pad = (cout + 63) / 64 * 64;
+        a.cout_pad = mvlm_fast_cout_pad(cout);
         const size_t n16 = size_t(a.cin_pad / 16) * 9 * 2 * splits * a.cout_pad * 8;
         wq = static_cast<unsigned short*>(ctx->get_scratch("conv_bench.wq", n16 * 2));
         if (!wq || !mvlm_conv_fast_ok(a, splits)) {

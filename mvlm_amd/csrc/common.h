@@ -301,7 +301,7 @@ const char* mvlm_conv_variant_name_impl(int v);
 // channel paddings of the opt-in bf16x3 kernel (its split weights are packed separately from the exact ones): 16-channel
 // k-chunks, 64-channel tiles.  Served: 16..256 input channels, output padding waste of at most 1.6x (84 -> 128 yes, 32 -> 64 no).
 inline int mvlm_fast_cin_pad(int cin) { return (cin + 15) / 16 * 16; }
-inline int mvlm_fast_cout_pad(int cout) { return (cout + 63) / 64 * 64; }
+inline int mvlm_fast_cout_pad(int cout) { return cout <= 32 ? 32 : (cout + 63) / 64 * 64; }  // (32: the f16x2 form's 32-channel tile)
 inline bool mvlm_fast_channels_ok(int cin, int cout) {
     return cin >= 16 && cin <= 256 && cout > 0 && cout * 8 >= mvlm_fast_cout_pad(cout) * 5;
 }

@@ -99,11 +99,13 @@ struct Split<2> {
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-// COUT_T output channels x (TRI rows x 32 pixels); 8 waves = 2 channel halves x 4 groups of TRI / 4 rows
+// COUT_T output channels x (TRI rows x 32 pixels); 8 waves = WM channel groups x WN row groups (2 x 4; the 32-channel tile
+// of the f16x2 form: 1 x 8 - conv2.conv2 / conv2.conv3 / conv3.conv2 / conv3.conv3 of the stem, 4.2 ms per 96 views on exact tiles)
 template <int COUT_T, int TRI, int NS = 3>
 struct FastCfg {
-    static constexpr int MT = COUT_T / 64;               // 32-row MFMA tiles per wave (channels)
-    static constexpr int NT = TRI / 4;                    // 32-pixel row segments per wave
+    static constexpr int WM = COUT_T >= 64 ? 2 : 1, WN = 8 / WM;
+    static constexpr int MT = COUT_T / (32 * WM);        // 32-row MFMA tiles per wave (channels)
+    static constexpr int NT = TRI / WN;                   // 32-pixel row segments per wave
     static constexpr int PH = TRI + 2, NPIX = FT_PW * PH;  // haloed tile
     static constexpr int X_BYTES = 2 * NS * NPIX * 16;      // [k-half][split][pixel][8 ch]
     static constexpr int W_BYTES = 3 * 2 * NS * COUT_T * 16;  // one tap row: [tap][k-half][split][cout][8 ch]
@@ -112,7 +114,8 @@ struct FastCfg {
     static constexpr int TAP_MFMAS = Split<NS>::NTERMS * MT * NT;  // per tap and wave
     static constexpr size_t LDS = size_t(2) * X_BYTES + size_t(2) * W_BYTES + 4 * 256 * sizeof(float);  // + BatchNorm table + as many zeros
     static_assert(LDS <= 160 * 1024, "stages must fit the CU's LDS");
-    static_assert(TAP_MFMAS == (NS == 3 ? 24 : 12), "the staging schedules below are written for 24 (bf16x3) / 12 (f16x2) MFMAs per tap");
+    static_assert(TAP_MFMAS == (NS == 3 ? 24 : 12) || (NS == 2 && TAP_MFMAS == 6),
+                  "the staging schedules below are written for 24 (bf16x3) / 12 (f16x2) / 6 (f16x2, 32 channels) MFMAs per tap");
     static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
 };
 
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     float* const sbn = reinterpret_cast<float*>(sW + 2 * W_BYTES);  // [128 channel pairs][scale, scale, shift, shift], then 512 zeros
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % C::WM, wn = wave / C::WM;
 
     int lid;
     {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     int wdst[W_ITERS];
 #pragma unroll
     for (int i = 0; i < W_ITERS; ++i) {
-        const int f0 = tid + i * FT_THREADS, f = f0 < W_ITEMS ? f0 : tid;
+        const int f0 = tid + i * FT_THREADS, f = f0 < W_ITEMS ? f0 : tid % W_ITEMS;  // (the 32-channel tile has fewer items than threads)
         const int seg = f / COUT_T, c = f - seg * COUT_T;
         wsrc[i] = unsigned((seg * a.cout_pad + co0 + c) * 8);
         wdst[i] = f * 16;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     // A fragment of MFMA tile m: output channel wm * 32 MT + 32 m + l31, k-half = half
     int aoff[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) aoff[m] = (half * NS * COUT_T + wm * 32 * MT + 32 * m + l31) * 16;
+    for (int m = 0; m < MT; ++m) aoff[m] = (half * NS * COUT_T + wm * 32 * MT + 32 * m + l31) * 16;  // (wm < WM)
 
     // ---- prologue: BatchNorm table, chunk 0's activations, unit 0's weights ----------------------------------------------
     // [channel pair][scale, scale, shift, shift]; without BatchNorm: 1, 0 (and no ReLU: relu_floor); then the zeros
@@ -352,7 +355,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 // slot tables: bf16x3 has 72 slots per unit, f16x2 has 36 - the same micro-operations (one split fewer) at
                 // half the distance.  W stores in tap 1; item 0 during ROW 1; items 1 and 2 during ROW 2; an item's splits are
                 // stored after its four channel pairs have been converted, the next item's conversion starts after that.
-                constexpr int WQ0 = NS == 3 ? 24 : 12, WQS = NS == 3 ? 4 : 2;
+                // (TAPM == 6, the 32-channel tile: 18 slots, one weight item, three activation items)
+                constexpr bool T6 = TAPM == 6;
+                constexpr int WQ0 = T6 ? 6 : (NS == 3 ? 24 : 12), WQS = T6 ? 1 : (NS == 3 ? 4 : 2);
                 if constexpr (q >= WQ0 && q < WQ0 + WQS * W_ITERS && (q - WQ0) % WQS == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     store_w(std::integral_constant<int, (q - WQ0) / WQS>{}, u + 1);
@@ -369,12 +374,12 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                     load_w(u + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                constexpr int C0 = NS == 3 ? 2 : 1, C0S = NS == 3 ? 6 : 3;      // ROW 1, item 0: pairs at C0 + C0S j
-                constexpr int S0 = NS == 3 ? 44 : 20, S0S = NS == 3 ? 6 : 4;    //               stores at S0 + S0S sp
-                constexpr int C1 = NS == 3 ? 2 : 1, C1S = NS == 3 ? 4 : 2;      // ROW 2, item 1
-                constexpr int S1 = NS == 3 ? 18 : 9, S1S = NS == 3 ? 2 : 1;
-                constexpr int C2 = NS == 3 ? 28 : 18, C2S = NS == 3 ? 4 : 2;    // ROW 2, item 2
-                constexpr int S2 = NS == 3 ? 60 : 28, S2S = NS == 3 ? 4 : 2;
+                constexpr int C0 = T6 ? 1 : (NS == 3 ? 2 : 1), C0S = T6 ? 1 : (NS == 3 ? 6 : 3);      // ROW 1, item 0: pairs at C0 + C0S j
+                constexpr int S0 = T6 ? 10 : (NS == 3 ? 44 : 20), S0S = T6 ? 2 : (NS == 3 ? 6 : 4);    //               stores at S0 + S0S sp
+                constexpr int C1 = T6 ? 1 : (NS == 3 ? 2 : 1), C1S = T6 ? 1 : (NS == 3 ? 4 : 2);      // ROW 2, item 1
+                constexpr int S1 = T6 ? 5 : (NS == 3 ? 18 : 9), S1S = T6 ? 1 : (NS == 3 ? 2 : 1);
+                constexpr int C2 = T6 ? 9 : (NS == 3 ? 28 : 18), C2S = T6 ? 1 : (NS == 3 ? 4 : 2);    // ROW 2, item 2
+                constexpr int S2 = T6 ? 14 : (NS == 3 ? 60 : 28), S2S = T6 ? 1 : (NS == 3 ? 4 : 2);
                 if constexpr (ROW == 1) {
                     if constexpr (q >= C0 && q < C0 + 4 * C0S && (q - C0) % C0S == 0) {
                         convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - C0) / C0S>{}, chunk + 1);
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
 template <int COUT_T, int TRI, bool GEN, int NS>
 int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
     using C = FastCfg<COUT_T, TRI, NS>;
-    const int bit = (NS == 3 ? 60 : 56) + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0);
+    const int bit = COUT_T == 32 ? 54 + (GEN ? 1 : 0) : (NS == 3 ? 60 : 56) + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0);
     if (!((ctx->conv_attr_mask >> bit) & 1ull)) {
         MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<COUT_T, TRI, GEN, NS>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS)));
@@ -577,6 +582,10 @@ int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
 
 template <int NS>
 int launch_fast_ns(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_dev) {
+    if constexpr (NS == 2) {
+        if (a.cout_pad == 32)
+            return (a.cin != a.cin_pad || a.res2) ? launch_fast<32, 16, true, 2>(ctx, a, wq_dev) : launch_fast<32, 16, false, 2>(ctx, a, wq_dev);
+    }
     if (a.cin != a.cin_pad || a.res2)
         return a.cout_pad % 128 == 0 ? launch_fast<128, 8, true, NS>(ctx, a, wq_dev) : launch_fast<64, 16, true, NS>(ctx, a, wq_dev);
     return a.cout_pad % 128 == 0 ? launch_fast<128, 8, false, NS>(ctx, a, wq_dev) : launch_fast<64, 16, false, NS>(ctx, a, wq_dev);
@@ -588,6 +597,7 @@ int launch_fast_ns(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_de
 bool mvlm_conv_fast_ok(const ConvArgs& a, int splits) {
     if (a.ksize != 3 || !mvlm_fast_channels_ok(a.cin, a.cout)) return false;
     // 128-channel tiles cover 8 rows, 64-channel tiles 16 rows (same matrix work per staged input tile)
+    if (mvlm_fast_cout_pad(a.cout) == 32 && splits != 2) return false;  // the 32-channel tile exists in the f16x2 form only
     const int rows = mvlm_fast_cout_pad(a.cout) % 128 == 0 ? 8 : 16;
     // plain NCHW output, or the up-path form: 2x2 scatter into the skip tensor (a residual block's layer: one residual, no
     // bias).  The f16x2 form only: its K loop is short enough for the unoverlapped scatter to pay (rb20.conv1 2089 -> 785 us,

@@ -205,7 +205,7 @@ def pack_fast_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_channel
         # the kernel's own paddings and limits (mvlm_fast_cin_pad / mvlm_fast_cout_pad / mvlm_fast_channels_ok, common.h)
         cin_pad, cout_pad = _round_up(s.cin, 16), _round_up(s.cout, 64)
         if not s.present or s.ksize != 3 or not 16 <= s.cin <= 256 or s.cout * 8 < cout_pad * 5:
-            continue
+            continue  # (the 32-channel layers: the f16x2 form only, pack_fast16_for_device)
         w = np.ascontiguousarray(sd[f"{s.name}.weight"], dtype=np.float32)
         n = int(lib.mvlm_pack_fast_weights(_lib.as_ptr(w, C.c_float), s.cout, s.cin, cout_pad, cin_pad, None))
         if n == 0:
@@ -235,7 +235,8 @@ def pack_fast16_for_device(sd: dict[str, np.ndarray], n_landmarks: int, in_chann
     unscale = np.ones(len(slots), dtype=np.float32)
     parts, cursor = [], 0
     for s in slots:
-        cin_pad, cout_pad = _round_up(s.cin, 16), _round_up(s.cout, 64)
+        # (mvlm_fast_cout_pad: this form has a 32-channel tile, so layers with up to 32 output channels pad to 32)
+        cin_pad, cout_pad = _round_up(s.cin, 16), (32 if s.cout <= 32 else _round_up(s.cout, 64))
         if not s.present or s.ksize != 3 or not 16 <= s.cin <= 256 or s.cout * 8 < cout_pad * 5:
             continue
         w = np.ascontiguousarray(sd[f"{s.name}.weight"], dtype=np.float32)

@@ -420,6 +420,9 @@ def test_end_to_end_matrix_over_seeds(dataset, mode, n_views, grid, seed):
     (256, 84, 64, 1, dict(bias=True)),                 # conv6 / conv10: 84 output channels in one 128-channel tile
     (128, 128, 32, 1, dict(pre=True, scale=1e-3)),     # small weights: the per-layer power-of-two scale
     (64, 128, 32, 1, dict(pre=True, scale=300.0, xscale=50.0)),   # large weights and activations, still inside fp16
+    (64, 32, 64, 2, dict(pre=True, res=True)),         # the 32-channel tile (1 x 8 waves, 18-slot staging): conv2.conv2 / conv3.conv2
+    (32, 32, 32, 3, dict(pre=True, res=True)),         # ... conv2.conv3 / conv3.conv3: two chunks
+    (48, 24, 32, 1, dict(bias=True)),                  # ... 24 of its 32 channels
 ])
 def test_fast16_conv_matches_torch(cin, cout, size, batch, opts):
     """mvlm_conv2d_fast16 (two fp16 terms per operand, 3 cross products, fp32 accumulation, weights scaled by the layer's
@@ -516,6 +519,9 @@ def test_fast16_serves_the_up_path_blocks():
     assert all("f16x2" in v16[k] for k in up), {k: v16[k] for k in up}
     assert not any("bf16x3" in v3[k] for k in up), {k: v3[k] for k in up}
     assert "f16x2" in v16["hg1.rb19.conv1"] and "bf16x3" in v3["hg1.rb19.conv1"]  # the plain blocks: both forms
+    stem32 = ["conv2.conv2", "conv2.conv3", "conv3.conv2", "conv3.conv3"]  # 64 -> 32 and 32 -> 32 channels: the f16x2 form's 32-channel tile
+    assert all("f16x2" in v16[k] for k in stem32), {k: v16[k] for k in stem32}
+    assert not any("bf16x3" in v3[k] for k in stem32), {k: v3[k] for k in stem32}
 
 
 @pytest.mark.parametrize("name,mode,n_views", [("dtu3d", "RGB", 16), ("bu3dfe", "RGB+depth", 12)])
