@@ -51,4 +51,9 @@ P=$ROOT/gpurun_out/prof_${TAG}_12views
 cp $P/kernel_stats.csv $OUT/${TAG}_12views_kernel_stats.csv
 cp $P/pmc_summary.txt $OUT/${TAG}_12views_pmc_summary.txt
 cp $P/traffic.json $OUT/${TAG}_12views_traffic.json
+echo "== rasteriser alone (per-kernel times, six cases) and the kernels of configs[4]" ; date
+timeout -k 10 300 bash tools/raster_trace.sh raster_$TAG > /dev/null 2>&1 || exit 1
+(cat $ROOT/gpurun_out/raster_$TAG/bench.txt; echo; cat $ROOT/gpurun_out/raster_$TAG/kernels.txt) > $OUT/${TAG}_raster_trace.txt
+timeout -k 10 300 bash tools/probes/profile_mediapipe_config.sh > /dev/null 2>&1 || exit 1
+cut -c1-260 $ROOT/gpurun_out/mp478/kernel_stats.csv | head -24 > $OUT/${TAG}_mediapipe_kernel_stats.csv
 date; ls -la $OUT
