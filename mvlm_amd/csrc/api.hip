@@ -97,20 +97,24 @@ extern "C" const char* mvlm_last_error(mvlm_ctx* ctx) {
 // A context owns grow-only scratch (render bins and keys, transformed vertices, fusion staging) that its kernels reuse from
 // call to call: safe while the calls are ordered on one stream.  Callers that move a context to ANOTHER stream (two
 // pipelines of one device under different torch streams share the process-wide context) get that order kept for them: the
-// new stream waits for everything the context enqueued on the previous one.
+// new stream waits for everything the context enqueued before.  The event it waits for was recorded at the END of the
+// previous entry points (MvlmOrderGuard), never here on the previous stream's handle - its owner may have destroyed that
+// stream since.  Only the very first change records here: until then the context has lived on the stream it was created
+// with, the null stream, which is never destroyed.
 extern "C" int mvlm_set_stream(mvlm_ctx* ctx, void* hip_stream) {
     MVLM_ENTER(ctx);
     hipStream_t next = static_cast<hipStream_t>(hip_stream);
-    if (next != ctx->stream && ctx->work_enqueued) {
+    if (next != ctx->stream) {
         if (!ctx->switch_event) MVLM_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
-        if (hipEventRecord(ctx->switch_event, ctx->stream) == hipSuccess)
-            MVLM_CHECK_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_event, 0));
-        else
-            (void)hipGetLastError();  // the previous stream no longer exists (its owner destroyed it): its work is done
+        if (!ctx->track_order) {
+            MVLM_CHECK_HIP(ctx, hipEventRecord(ctx->switch_event, ctx->stream));  // (ctx->stream is still the null stream)
+            ctx->order_recorded = true;
+            ctx->track_order = true;
+        }
+        if (ctx->order_recorded) MVLM_CHECK_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_event, 0));
     }
     ctx->stream = next;
-    ctx->work_enqueued = true;  // (whoever sets a stream is about to enqueue on it)
-    return 0;
+    return 0;  // (the guard now records the event on the new stream: harmless, and it keeps "recorded" true)
 }
 
 extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {

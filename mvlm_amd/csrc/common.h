@@ -24,6 +24,7 @@
 // current device (a process may hold contexts for several GPUs)
 #define MVLM_ENTER(ctx)                               \
     std::lock_guard<std::mutex> _mvlm_lock((ctx)->mu); \
+    MvlmOrderGuard _mvlm_order{(ctx)};                 \
     MVLM_CHECK_HIP(ctx, hipSetDevice((ctx)->device))
 
 #define MVLM_REQUIRE(ctx, cond, msg)                                                         \
@@ -212,8 +213,13 @@ struct mvlm_ctx {
     // its side stream while it issues the branch of the graph that runs beside the main one (cnn_graph.hip)
     hipStream_t launch_stream = nullptr;
     hipStream_t cur_stream() const { return launch_stream ? launch_stream : stream; }
-    hipEvent_t switch_event = nullptr;  // mvlm_set_stream: orders the context's work across a change of stream
-    bool work_enqueued = false;
+    // mvlm_set_stream: orders the context's work across a change of stream.  A context that has only ever run on the null
+    // stream (which cannot be destroyed) records nothing; from its first change of stream on, every entry point leaves
+    // switch_event behind the work it enqueued (MvlmOrderGuard), so a later change never touches the previous stream's
+    // handle - its owner may have destroyed it by then.
+    hipEvent_t switch_event = nullptr;
+    bool track_order = false;      // the context has been moved between streams: record switch_event at every exit
+    bool order_recorded = false;   // switch_event stands behind everything enqueued so far
     std::mutex mu;
     std::string err;
     CnnState cnn;
@@ -275,6 +281,19 @@ inline int mvlm_ctx::fail(const std::string& m) {
     mvlm_thread_error_ctx() = this;
     return 1;
 }
+
+// End of every entry point (declared by MVLM_ENTER, destroyed before the context's mutex is released): once a context has
+// been moved between streams, leave switch_event behind whatever this call enqueued on the current one.
+struct MvlmOrderGuard {
+    mvlm_ctx* ctx;
+    ~MvlmOrderGuard() {
+        if (!ctx->track_order || !ctx->switch_event) return;
+        if (hipEventRecord(ctx->switch_event, ctx->stream) == hipSuccess)
+            ctx->order_recorded = true;
+        else
+            (void)hipGetLastError();
+    }
+};
 
 // a mesh's device copy is complete once its `ready` event has fired: consumers make their stream wait for it
 inline int mvlm_mesh_wait_ready(mvlm_ctx* ctx, const mvlm_mesh* m, hipStream_t stream) {

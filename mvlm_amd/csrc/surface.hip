@@ -26,7 +26,9 @@ __device__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
     const double d3 = dot(ab, bp), d4 = dot(ac, bp);
     if (d3 >= 0 && d4 <= d3) return b;
     const double vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) return madd(a, ab, d1 / (d1 - d3));
+    // (d1 - d3 = |ab|^2: a triangle with a == b is the segment ac - vtkCleanPolyData turns it into a line cell - and belongs
+    //  to the edge-ac branch below, not to a 0 / 0 here)
+    if (vc <= 0 && d1 >= 0 && d3 <= 0 && d1 - d3 > 0) return madd(a, ab, d1 / (d1 - d3));
     const V3 cp = sub(p, c);
     const double d5 = dot(ab, cp), d6 = dot(ac, cp);
     if (d6 >= 0 && d5 <= d6) return c;
@@ -39,37 +41,102 @@ __device__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
     return {a.x + ab.x * v + ac.x * w, a.y + ab.y * v + ac.y * w, a.z + ab.z * v + ac.z * w};
 }
 
-// Pass 0: an upper bound on every landmark's squared distance to the surface - its distance to the nearest VERTEX (a
-// vertex is a point of the surface).  BOUND_SPLIT workgroups per landmark stride over the vertices (0.6 MB, L2-resident),
-// four loads in flight per thread; the minimum goes to ub[] with an atomic min on the bit pattern (non-negative doubles
-// order like their bits).  ub[] starts at 0x7f7f... = 1.4e306, "no bound": it stays there for a non-finite landmark,
-// whose comparisons are all false.
+// Pass 0: an upper bound on every landmark's squared distance to the surface.  The nearest vertex THAT A TRIANGLE USES
+// (vert_tri[v] = lowest id of a triangle with corner v, filled by project_soup_kernel; VERT_UNUSED = a stray point of the
+// file, which the .ply / .vtk / .stl / .wrl readers and mvlm_mesh_upload keep and which is no point of the surface - the
+// reference drops such points in vtkCleanPolyData and searches cells only, estimator3d.py:258-270) names a candidate
+// triangle; the bound is the exact walk's OWN squared distance to that triangle (project_bound_pick_kernel), i.e. a value
+// the search below will meet again - so whatever the walk makes of a degenerate triangle, the bound never lies below the
+// winner.  A candidate whose walk gives no finite distance leaves "no bound" (0x7f7f... = 1.4e306: nothing is skipped), and
+// so does a non-finite landmark, whose comparisons are all false.
+// BOUND_SPLIT workgroups per landmark stride over the vertices (0.6 MB, L2-resident), four loads in flight per thread;
+// every workgroup leaves its (distance, vertex) minimum, lowest vertex on ties.
 constexpr int BOUND_SPLIT = 8;
+constexpr int VERT_UNUSED = 0x7f7f7f7f;  // what hipMemsetAsync(.., 0x7f, ..) leaves: above every triangle id
 __global__ __launch_bounds__(256) void project_bound_kernel(const float* __restrict__ verts, int n_verts,
-                                                            const double* __restrict__ pts, unsigned long long* __restrict__ ub) {
+                                                            const int* __restrict__ vert_tri, const double* __restrict__ pts,
+                                                            double* __restrict__ cand_d, int* __restrict__ cand_v) {
+    __shared__ double s_d[4];
+    __shared__ int s_v[4];
     const int lm = blockIdx.x;
     const V3 p = {pts[lm * 3], pts[lm * 3 + 1], pts[lm * 3 + 2]};
     double best = INFINITY;
+    int best_v = 0x7fffffff;
     const int stride = BOUND_SPLIT * 256;
     for (int v0 = blockIdx.y * 256 + threadIdx.x; v0 < n_verts; v0 += 4 * stride) {
         V3 q[4];
+        int used[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int v = min(v0 + k * stride, n_verts - 1);  // (a repeated vertex changes no minimum)
             q[k] = V3{verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]};
+            used[k] = vert_tri[v];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const V3 d = sub(q[k], p);
             const double d2 = dot(d, d);
-            best = d2 < best ? d2 : best;  // (NaN never wins)
+            if (used[k] != VERT_UNUSED && d2 < best) {  // ascending v per thread: first minimum (NaN never wins)
+                best = d2;
+                best_v = min(v0 + k * stride, n_verts - 1);
+            }
         }
     }
     for (int s = 32; s >= 1; s >>= 1) {
-        const double o = __shfl_down(best, s);
-        best = o < best ? o : best;
+        const double od = __shfl_down(best, s);
+        const int ov = __shfl_down(best_v, s);
+        if (od < best || (od == best && ov < best_v)) {
+            best = od;
+            best_v = ov;
+        }
     }
-    if ((threadIdx.x & 63) == 0 && best < INFINITY) atomicMin(&ub[lm], (unsigned long long)__double_as_longlong(best));
+    if ((threadIdx.x & 63) == 0) {
+        s_d[threadIdx.x >> 6] = best;
+        s_v[threadIdx.x >> 6] = best_v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_d[w] < best || (s_d[w] == best && s_v[w] < best_v)) {
+                best = s_d[w];
+                best_v = s_v[w];
+            }
+        cand_d[lm * BOUND_SPLIT + blockIdx.y] = best;
+        cand_v[lm * BOUND_SPLIT + blockIdx.y] = best_v;
+    }
+}
+
+// ... and the bound itself: one thread per landmark takes the nearest used vertex of the BOUND_SPLIT candidates and walks
+// the triangle that vertex stands for.
+__global__ __launch_bounds__(64) void project_bound_pick_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tris,
+                                                                const int* __restrict__ vert_tri, const double* __restrict__ pts,
+                                                                int n_points, const double* __restrict__ cand_d,
+                                                                const int* __restrict__ cand_v, unsigned long long* __restrict__ ub) {
+    const int lm = blockIdx.x * 64 + threadIdx.x;
+    if (lm >= n_points) return;
+    double best = INFINITY;
+    int best_v = 0x7fffffff;
+    for (int k = 0; k < BOUND_SPLIT; ++k) {
+        const double od = cand_d[lm * BOUND_SPLIT + k];
+        const int ov = cand_v[lm * BOUND_SPLIT + k];
+        if (od < best || (od == best && ov < best_v)) {
+            best = od;
+            best_v = ov;
+        }
+    }
+    unsigned long long bound = 0x7f7f7f7f7f7f7f7full;  // "no bound"
+    if (best_v != 0x7fffffff) {
+        const int t = vert_tri[best_v];
+        const int ia = tris[3 * t], ib = tris[3 * t + 1], ic = tris[3 * t + 2];
+        const V3 p = {pts[lm * 3], pts[lm * 3 + 1], pts[lm * 3 + 2]};
+        const V3 a = {verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]};
+        const V3 b = {verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]};
+        const V3 c = {verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]};
+        const V3 d = sub(closest_on_triangle(p, a, b, c), p);
+        const double d2 = dot(d, d);
+        if (d2 < 1e300) bound = (unsigned long long)__double_as_longlong(d2);  // (false for NaN / inf)
+    }
+    ub[lm] = bound;
 }
 
 // The triangles once more, de-indexed and component-major: soup[e * n_tris + t], e = 0..8 = a.xyz, b.xyz, c.xyz.
@@ -77,13 +144,15 @@ __global__ __launch_bounds__(256) void project_bound_kernel(const float* __restr
 // four scattered loads per triangle and group, and the L1s' rate for scattered lines - not the arithmetic - set its
 // time (7 us per 1 024 triangles and CU).  One gather pass per call (3.6 MB for 99 458 triangles) makes all of them
 // coalesced streams.
+// The same pass notes for every vertex the lowest triangle that uses it (vert_tri, cleared to VERT_UNUSED before).
 __global__ __launch_bounds__(256) void project_soup_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tris,
-                                                           int n_tris, float* __restrict__ soup) {
+                                                           int n_tris, float* __restrict__ soup, int* __restrict__ vert_tri) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_tris) return;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         const int i = tris[3 * t + e];
+        atomicMin(&vert_tri[i], t);
 #pragma unroll
         for (int d = 0; d < 3; ++d) soup[size_t(3 * e + d) * n_tris + t] = verts[3 * i + d];
     }
@@ -368,12 +437,18 @@ extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, con
     auto* part_t = static_cast<int*>(ctx->get_scratch("project.part_t", size_t(n_points) * n_chunks * sizeof(int)));
     auto* ub = static_cast<unsigned long long*>(ctx->get_scratch("project.ub", size_t(n_points) * sizeof(unsigned long long)));
     auto* soup = static_cast<float*>(ctx->get_scratch("project.soup", size_t(9) * mesh->n_tris * sizeof(float)));
-    MVLM_REQUIRE(ctx, part_d && part_t && ub && soup, "project_to_surface: scratch allocation failed");
+    auto* vert_tri = static_cast<int*>(ctx->get_scratch("project.vert_tri", size_t(mesh->n_verts) * sizeof(int)));
+    auto* cand_d = static_cast<double*>(ctx->get_scratch("project.cand_d", size_t(n_points) * BOUND_SPLIT * sizeof(double)));
+    auto* cand_v = static_cast<int*>(ctx->get_scratch("project.cand_v", size_t(n_points) * BOUND_SPLIT * sizeof(int)));
+    MVLM_REQUIRE(ctx, part_d && part_t && ub && soup && vert_tri && cand_d && cand_v, "project_to_surface: scratch allocation failed");
     MVLM_REQUIRE(ctx, n_points <= 65535, "project_to_surface: at most 65535 points per call");
-    MVLM_CHECK_HIP(ctx, hipMemsetAsync(ub, 0x7f, size_t(n_points) * sizeof(unsigned long long), ctx->stream));  // 1.4e306: "no bound yet"
-    hipLaunchKernelGGL(project_bound_kernel, dim3(n_points, BOUND_SPLIT), dim3(256), 0, ctx->stream, mesh->verts, mesh->n_verts, pts_dev, ub);
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(vert_tri, 0x7f, size_t(mesh->n_verts) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(project_soup_kernel, dim3((mesh->n_tris + 255) / 256), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris,
-                       mesh->n_tris, soup);
+                       mesh->n_tris, soup, vert_tri);
+    hipLaunchKernelGGL(project_bound_kernel, dim3(n_points, BOUND_SPLIT), dim3(256), 0, ctx->stream, mesh->verts, mesh->n_verts,
+                       vert_tri, pts_dev, cand_d, cand_v);
+    hipLaunchKernelGGL(project_bound_pick_kernel, dim3((n_points + 63) / 64), dim3(64), 0, ctx->stream, mesh->verts, mesh->tris,
+                       vert_tri, pts_dev, n_points, cand_d, cand_v, ub);
     hipLaunchKernelGGL(project_partial_kernel, dim3(n_chunks, n_groups), dim3(256), 0, ctx->stream, soup, mesh->n_tris, pts_dev,
                        n_points, ub, n_chunks, n_sub, part_d, part_t);
     hipLaunchKernelGGL(project_final_kernel, dim3(n_points), dim3(64), 0, ctx->stream, mesh->verts, mesh->tris, pts_dev,

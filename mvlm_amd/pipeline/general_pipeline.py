@@ -347,14 +347,18 @@ class Pipeline(abc.ABC):
             landmarks = host[: nl_all * 24].view(np.float64).reshape(nl_all, 3).copy()
             error = e3.mean_error(host[nl_all * 24: nl_all * 32].view(np.float64))
             r3.check()  # deferred renderer status (the .cpu() above already synchronised)
-        if getattr(p2, "precision", None) == "fast16" and (parallel.any_rank(p2.fast16_overflowed(), self.device) if sharded
-                                                           else p2.fast16_overflowed()):
+        asked16 = getattr(p2, "configured_precision", getattr(p2, "precision", None)) == "fast16"
+        if asked16:
             # an activation beyond fp16's range somewhere in the network (the kernel raised the context's flag; the maxima of
             # the pass carry NaN scores, which survive no filter - the landmarks above are finite nonsense).  Same scan again
             # on bf16x3; asked here, after the step's own wait for its results, the question costs one 4-byte copy.
-            # (the global RNG stands behind this call's draws: the repeat draws again, as a second call would; sharded: the
-            #  decision is taken by all ranks together - a rank repeating alone would wait in collectives nobody else joins)
-            return p2.repeat_without_fp16(lambda: self.predict_mesh_device(mesh, transform_stack))
+            # (the global RNG stands behind this call's draws: the repeat draws again, as a second call would.)
+            # Sharded: the decision is taken by all ranks together - a rank repeating alone would wait in collectives nobody
+            # else joins - and WHETHER to ask is decided from what the caller configured, which is the same on every rank:
+            # a rank that already fell back on its own (predict_landmarks_from_images) still joins the all-reduce.
+            mine = p2.precision == "fast16" and p2.fast16_overflowed()
+            if parallel.any_rank(mine, self.device) if sharded else mine:
+                return p2.repeat_without_fp16(lambda: self.predict_mesh_device(mesh, transform_stack))
         self._say("Landmarks [Error]: ", f"{error:08.6f}", " mm")
         self.last_error = error
         return landmarks, error

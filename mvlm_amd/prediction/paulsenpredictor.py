@@ -91,6 +91,7 @@ class HipPaulsenModel(Predictor2D):
         self._fast_loaded = False
         self._fast16_loaded = False
         self.fast16_fallbacks = 0  # passes repeated with "fast" because an activation left fp16's range
+        self._fast16_seen = False  # an overflow met in an earlier library call of the current pass (see _maxima_on)
         self.precision = "exact"
         self.set_precision(precision)
 
@@ -141,6 +142,9 @@ class HipPaulsenModel(Predictor2D):
         for ctx in holders:
             ctx.check(ctx.lib.mvlm_cnn_set_precision(ctx.handle, {"exact": 0, "fast": 1, "fast16": 2}[precision]))
         self.precision = precision
+        # what the CALLER asked for (repeat_without_fp16 restores it): the same on every rank of a sharded job, unlike
+        # ``precision``, which a rank's own fallback changes - collectives are decided from this one
+        self.configured_precision = precision
 
     @abc.abstractmethod
     def get_lm_count(self) -> int:
@@ -226,6 +230,12 @@ class HipPaulsenModel(Predictor2D):
             ctx.check(ctx.lib.mvlm_heatmap_maxima(ctx.handle, C.c_void_p(heat.data_ptr()), nb, nl, 256,
                                                   1, C.c_void_p(part.data_ptr())))
             maxima[:, s:s + nb] = part
+            if self.precision == "fast16":
+                # every mvlm_cnn_heatmaps call starts with a clear range flag: an overflow in THIS slice has to be noted
+                # before the next slice's call erases it
+                v = C.c_int(0)
+                ctx.check(ctx.lib.mvlm_cnn_fast16_overflowed(ctx.handle, C.byref(v)))
+                self._fast16_seen = self._fast16_seen or bool(v.value)
 
     def predict_device(self, image_stack_dev, out=None):
         """torch f32 [N,256,256,4] on this GPU -> maxima torch f32 [NL,N,3] on the GPU (written into ``out``
@@ -239,6 +249,7 @@ class HipPaulsenModel(Predictor2D):
         dev = torch.device("cuda", self.ctx.device)
         if image_stack_dev.dtype != torch.float32 or tuple(image_stack_dev.shape[1:]) != (256, 256, 4):
             raise RuntimeError(f"Unexpected image stack shape: {tuple(image_stack_dev.shape)} {image_stack_dev.dtype}")
+        self._fast16_seen = False  # range flag of THIS pass (slices of a materialised "moment" pass add to it)
         x = image_stack_dev.contiguous()
         n = int(x.shape[0])
         nl = self.get_lm_count()
@@ -336,7 +347,7 @@ class HipPaulsenModel(Predictor2D):
     def fast16_overflowed(self) -> bool:
         """Did the last "fast16" pass meet an activation outside fp16's range (on any replica)?  Waits for the passes; ask
         after the results have been fetched."""
-        hit = False
+        hit = self._fast16_seen
         for ctx in [self.ctx] + [r.ctx for r in self._replicas]:
             v = C.c_int(0)
             ctx.check(ctx.lib.mvlm_cnn_fast16_overflowed(ctx.handle, C.byref(v)))
@@ -349,7 +360,9 @@ class HipPaulsenModel(Predictor2D):
         again)."""
         print('Warning: an activation exceeded the fp16 range of precision="fast16" - repeating the pass with precision="fast"')
         self.fast16_fallbacks += 1
+        asked = self.configured_precision
         self.set_precision("fast")
+        self.configured_precision = asked
         return run()
 
 

@@ -37,7 +37,8 @@ def closest_point_on_triangles(p: np.ndarray, a: np.ndarray, b: np.ndarray, c: n
     with np.errstate(divide="ignore", invalid="ignore"):
         put((d1 <= 0) & (d2 <= 0), a)
         put((d3 >= 0) & (d4 <= d3), b)
-        put((vc <= 0) & (d1 >= 0) & (d3 <= 0), a + (d1 / (d1 - d3))[:, None] * ab)
+        # d1 - d3 = |ab|^2: a triangle with a == b is the segment ac (vtkCleanPolyData makes it a line cell) - edge ac below
+        put((vc <= 0) & (d1 >= 0) & (d3 <= 0) & (d1 - d3 > 0), a + (d1 / (d1 - d3))[:, None] * ab)
         put((d6 >= 0) & (d5 <= d6), c)
         put((vb <= 0) & (d2 >= 0) & (d6 <= 0), a + (d2 / (d2 - d6))[:, None] * ac)
         w = (d4 - d3) / ((d4 - d3) + (d5 - d6))
@@ -56,7 +57,9 @@ def project_landmarks_to_surface(verts: np.ndarray, tris: np.ndarray, landmarks:
     out = np.copy(landmarks)
     for i in range(landmarks.shape[0]):
         pts, d2 = closest_point_on_triangles(landmarks[i], a, b, c)
-        out[i] = pts[int(np.argmin(d2))]
+        d2 = np.where(np.isfinite(d2), d2, np.inf)  # a triangle the walk cannot evaluate (a == b == c with p = nan ...) never wins
+        if np.isfinite(d2).any():                   # (a non-finite landmark passes through unchanged)
+            out[i] = pts[int(np.argmin(d2))]
     return out
 
 
