@@ -28,7 +28,7 @@ __device__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
     const double vc = d1 * d4 - d3 * d2;
     // (d1 - d3 = |ab|^2: a triangle with a == b is the segment ac - vtkCleanPolyData turns it into a line cell - and belongs
     //  to the edge-ac branch below, not to a 0 / 0 here)
-    if (vc <= 0 && d1 >= 0 && d3 <= 0 && d1 - d3 > 0) return madd(a, ab, d1 / (d1 - d3));
+    if (vc <= 0 && d1 >= 0 && d3 <= 0 && d1 > d3) return madd(a, ab, d1 / (d1 - d3));
     const V3 cp = sub(p, c);
     const double d5 = dot(ab, cp), d6 = dot(ac, cp);
     if (d6 >= 0 && d5 <= d6) return c;
