@@ -244,7 +244,10 @@ def launch_ranks(n: int) -> int:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    # dmabuf IPC for the ranks' RCCL (mvlm_amd/parallel.py rccl_environment: the image exports it; a launcher that does not
+    # inherit the image's environment must carry it).  Written out here instead of imported: this parent imports nothing
+    # that could touch the GPU.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]

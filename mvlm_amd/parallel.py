@@ -76,6 +76,19 @@ def timing_summary() -> dict:
     return out
 
 
+def rccl_environment(env=None) -> dict:
+    """Environment a process needs BEFORE it initialises the GPU to take part in a multi-process RCCL job on this
+    platform: HSA_ENABLE_IPC_MODE_LEGACY=0 selects dmabuf IPC for ROCr's inter-process memory handles.  Source: the
+    deployment image this package is built for exports exactly that (its host kernel driver supports only dmabuf IPC;
+    with the legacy mode RCCL's and torch's cross-process buffer sharing fail with ``hipIpcGetMemHandle: invalid
+    argument``) - so a launcher that builds its children's environment from scratch must carry it over, and one that
+    inherits the image's environment gets the same value.  A value the caller has already set is kept.
+    Used by every place that starts RCCL ranks: bench.py's launcher, the nccl workers of the tests, INTEGRATION.md's recipe."""
+    env = os.environ if env is None else env
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
 def is_distributed() -> bool:
     """A process group with more than one rank exists.  MVLM_DIST_WORLD_OF_ONE=1 also counts a group of ONE rank: the
     rehearsal of the sharded path (same collectives, tensors and devices) over RCCL on a one-GPU box."""
@@ -171,6 +184,29 @@ def any_rank(flag: bool, device=None) -> bool:
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return bool(int(t.item()))
+
+
+def all_gather_valid(valid_local: np.ndarray | None, n_local: int, n_total: int, device=None) -> np.ndarray:
+    """Per-view validity of a sharded step (a detector that found nothing in some views, mediapipepredictor.py:38-41):
+    every rank's host mask [n_local] (None = all valid) -> the job's mask [n_total] in view order, one small tensor
+    collective.  Every rank must call it."""
+    mine = np.ones(n_local, bool) if valid_local is None else np.asarray(valid_local, bool)
+    if not is_distributed():
+        return mine
+    import torch
+    import torch.distributed as dist
+
+    rank, world = rank_world()
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    n_max = max(sizes)
+    dev = _collective_device(device)
+    send = torch.ones(n_max, dtype=torch.int32)
+    send[: len(mine)] = torch.from_numpy(mine.astype(np.int32))
+    send = send.to(dev)
+    recv = torch.empty(world * n_max, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    host = recv.cpu().numpy()
+    return np.concatenate([host[r * n_max: r * n_max + sizes[r]] for r in range(world)]).astype(bool)
 
 
 def all_gather_views(local, n_total: int):

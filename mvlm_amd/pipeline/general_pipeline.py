@@ -308,19 +308,36 @@ class Pipeline(abc.ABC):
         if self.render_image_stack and images is not None:
             self.visualize_image_stack(images.cpu().numpy(), mesh.path or Path("mesh.obj"), first_index=lo)
 
+        valid = None  # host bool [views of this rank]: a detector's "nothing found in this view" (None: all valid)
         with tm.stage("prediction"):
             if images is not None and isinstance(p2, HipPaulsenModel):
                 maxima = p2.predict_device(images, out=self._buffer("maxima", (p2.get_lm_count(), hi - lo, 3)))
             elif images is not None:
                 maxima = p2.predict_device(images)
+                if isinstance(maxima, tuple):
+                    maxima, valid = maxima
             else:
                 maxima = torch.empty((p2.get_lm_count(), 0, 3), dtype=torch.float32,
                                      device=torch.device("cuda", self.device))
             del images
             if sharded:
                 maxima = parallel.all_gather_views(maxima, n_total)
+                if not isinstance(p2, HipPaulsenModel):  # (same predictor class on every rank: all join or none does)
+                    valid = parallel.all_gather_valid(valid, hi - lo, n_total, self.device)
             if self.verbose:
                 torch.cuda.synchronize()
+        if valid is not None and not valid.all():
+            # views without a detection leave the call here, as in the reference (general_pipeline.py:93-95:
+            # landmark_stack[:, valid], transform_stack[valid]) - before rays, filter and the RANSAC draws, which
+            # address the remaining views by position
+            keep = np.nonzero(valid)[0]
+            maxima = maxima.index_select(1, torch.from_numpy(keep).to(maxima.device)).contiguous()
+            transform_stack = transform_stack[keep]
+            rot_dev = e3.upload_rotations(rot[keep])
+            n_total = int(len(keep))
+            if plan is not None:  # sharded: the draws planned for all views are void - plan again for the views that remain
+                np.random.set_state(plan["rng_state"])
+                plan = e3.plan_draws(nl_all, n_total, draws_fn)
 
         if plan is None:
             # the RANSAC draws for the expected survivor counts (~0.3 ms of numpy calls) are made now, while the GPU

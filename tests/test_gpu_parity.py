@@ -438,6 +438,9 @@ def _shard_worker(rank, world, port, obj, q, backend="gloo"):
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if backend == "nccl":  # = RCCL; the recipe of INTEGRATION.md "Multi-GPU"
+        from mvlm_amd import parallel
+
+        parallel.rccl_environment()  # the same environment bench.py's launcher gives its ranks (this child has not touched the GPU yet)
         os.environ["MVLM_DIST_WORLD_OF_ONE"] = "1"  # a group of one rank still takes the sharded path (parallel.is_distributed)
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
