@@ -57,7 +57,7 @@ def test_snap_ignores_stray_points_and_survives_degenerate_triangles(grid):
     assert np.isfinite(want).all()
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
     # none of the landmarks went to its stray point, and the answers are those of the mesh without the strays
-    assert np.linalg.norm(got[:n_q] - strays, axis=1).min() > 1.0
+    assert np.linalg.norm(got[:n_q] - strays.astype(np.float32), axis=1).min() > 1e-3
     clean = surface.project_landmarks_to_surface(np.concatenate([base.verts, extra_v.astype(np.float32)]),
                                                  np.concatenate([base.tris, extra_t - n_q]), pts)
     np.testing.assert_allclose(got, clean, rtol=0, atol=1e-9)
