@@ -52,6 +52,9 @@ struct Exec {
     int rc = 0;
     int arena = 0;        // arena new tensors come from = stream the next launches go to
     bool forked = false;
+    // MVLM_POOL_KERNEL_ONLY=1 (tests; launch-by-launch passes only - a captured graph keeps what it was captured with): every
+    // max_pool2d as its own launch behind the block, the form the fused epilogues are compared with bit for bit
+    const bool no_pool_fusion = [] { const char* e = getenv("MVLM_POOL_KERNEL_ONLY"); return e && e[0] == '1'; }();
 
     Exec(mvlm_ctx* c, int batch, void* w, size_t wb, bool d) : ctx(c), st(c->cnn), B(batch), ws((char*)w), ws_bytes(wb), dry(d) {}
 
@@ -380,7 +383,7 @@ struct Exec {
         bool fuse = PB.want_pool;
         for (int j = 0; j < 3; ++j) {
             pv[j] = pair_variant(PA.base + 1 + j, rb_input(PA, j), PA.a[j], PA.S, PB.base + 1 + j, rb_input(PB, j), PB.a[j], PB.S);
-            if (fuse) fuse = pv[j] >= 0 ? mvlm_conv_variant_can_pool(pv[j]) : pool_fusable(PB.base + 1 + j, rb_input(PB, j), PB.a[j], PB.S);
+            if (fuse) fuse = pv[j] >= 0 ? (!no_pool_fusion && mvlm_conv_variant_can_pool(pv[j])) : pool_fusable(PB.base + 1 + j, rb_input(PB, j), PB.a[j], PB.S);
         }
         set_pool(PB, fuse);
         for (int j = 0; j < 3; ++j)
@@ -404,6 +407,7 @@ struct Exec {
     // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
     bool pool_fusable(int slot, const Tensor& x, ConvArgs a, int S) {
         if (st.fast) return false;  // the split-operand kernels have no pooled output: the pool kernel follows the block
+        if (no_pool_fusion) return false;
         const int32_t* r = d(slot);
         a.cin = r[1];
         a.cout = r[2];

@@ -69,6 +69,14 @@ struct Cfg {
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
     static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
+    // fused 2x2 max-pool in the epilogue.  POOL32: the 32-pixel-row tiles - the rows of a pair are two pixel registers of a
+    // lane, the columns two neighbouring lanes.  POOL_SMALL (round 5): tiles narrower than 32 pixels (and the split-K tiles) -
+    // a 32-pixel MFMA column then holds 32 / TW consecutive rows of ONE image, so the row partner of lane l is lane l ^ TW and
+    // the column partner lane l ^ 1; TRI even keeps the pairs inside the tile.  max is exact: the pooled tensor is bit for bit
+    // what the pool kernel makes of the full-resolution one.
+    static constexpr bool POOL32 = !SPLITK && TW == 32 && NIMG == 1 && (PIX_T / 4 / 32) % 2 == 0 && COUT_T % 32 == 0;
+    static constexpr bool POOL_SMALL = TW < 32 && TRI % 2 == 0 && COUT_T % 32 == 0;
+    static constexpr bool CAN_POOL_ANY = POOL32 || POOL_SMALL;
     // variants that also exist as a two-problem launch (conv_pair_kernel): the tiles of the residual blocks' 3x3 convolutions
     static constexpr bool PAIRABLE = KS == 3 && COUT_T % 32 == 0 && COUT_T != 96 && !(SPLITK && PIX_T != 32);
     static_assert(SPLITK ? ((PIX_T == 32 || PIX_T == 64) && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
@@ -556,6 +564,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += sk.res[j];
                 }
+                if constexpr (C::POOL_SMALL) {
+                    if (a.pool_out) {  // (wave-uniform: every lane takes part in the exchanges)
+                        const unsigned o_pool = unsigned((sk.y >> 1) * (a.W >> 1) + (sk.x >> 1));
+                        const bool writer = sk.ok && (l31 & C::TW) == 0 && (l31 & 1) == 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float m1 = fmaxf(v[j], __shfl_xor(v[j], C::TW));  // the row below / above
+                            const int mi = __float_as_int(m1);
+                            const float m2 = fmaxf(m1, __int_as_float(__builtin_amdgcn_update_dpp(mi, mi, 0xB1, 0xf, 0xf, false)));  // lane ^ 1
+                            if (writer && cl + j < a.cout) a.pool_out[(size_t(sk.b) * a.pool_ctot + a.pool_coff + cl + j) * (HWo / 4) + o_pool] = m2;
+                        }
+                    }
+                }
                 if (a.out) {
                     if (!a.up_out) {
 #pragma unroll
@@ -743,7 +764,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     // fused 2x2 max-pool: the rows of a pair are two pixel registers of one lane (n, n+1), the columns two
     // neighbouring lanes, so it needs 32-pixel tile rows, one image per tile and an even row count per wave
     constexpr bool CAN_POOL = !C::SPLITK && C::TW == 32 && C::NIMG == 1 && C::NT % 2 == 0;
+    constexpr bool POOLS = C::POOL_SMALL;  // narrow tiles: partner lanes l ^ TW (row) and l ^ 1 (column), see Cfg
     unsigned o_pool[C::NT / 2 > 0 ? C::NT / 2 : 1];
+    unsigned o_pool_s[POOLS ? C::NT : 1];
+    const bool pool_writer = (l31 & (C::TW & 31)) == 0 && (l31 & 1) == 0;
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int p = (C::SPLITK ? 0 : wave * (C::PIX_T / 4)) + n * 32 + l31;
@@ -760,6 +784,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
         o_r2[n] = (bb * a.res2_ctot + a.res2_coff + h4) * HW + pix;
         if constexpr (CAN_POOL)
             if ((n & 1) == 0) o_pool[n / 2] = (bb * a.pool_ctot + a.pool_coff + h4) * (HW / 4) + unsigned((y >> 1) * (W >> 1) + (x >> 1));
+        if constexpr (POOLS) o_pool_s[n] = (bb * a.pool_ctot + a.pool_coff + h4) * (HW / 4) + unsigned((y >> 1) * (W >> 1) + (x >> 1));
         if (!a.up_out) {
             o_out[n] = (bb * a.out_ctot + a.out_coff + h4) * HW + pix;
             o_skip[n] = 0;
@@ -874,6 +899,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
                             const int vi = __float_as_int(v2);
                             const float other = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xf, 0xf, false));  // lane ^ 1
                             if (okc[j] && (l31 & 1) == 0) p[o_pool[q]] = fmaxf(v2, other);
+                        }
+                    }
+                }
+            }
+            if constexpr (POOLS) {
+                if (a.pool_out) {  // (wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* const p = t_pool + size_t(cs0 + j) * (HW / 4);
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n) {
+                            const float m1 = fmaxf(vals[j * C::NT + n], __shfl_xor(vals[j * C::NT + n], C::TW));
+                            const int mi = __float_as_int(m1);
+                            const float m2 = fmaxf(m1, __int_as_float(__builtin_amdgcn_update_dpp(mi, mi, 0xB1, 0xf, 0xf, false)));  // lane ^ 1
+                            if (okc[j] && lane_ok[n] && pool_writer) p[o_pool_s[n]] = m2;
                         }
                     }
                 }
@@ -1037,6 +1077,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
                     });
                 });
             }
+            if constexpr (POOL && POOLS) {
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    float* const p = a.pool_out + size_t(cs0 + j) * (HW / 4);
+                    static_for<0, C::NT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        const float m1 = fmaxf(vals[j * C::NT + n], __shfl_xor(vals[j * C::NT + n], C::TW));
+                        const int mi = __float_as_int(m1);
+                        const float m2 = fmaxf(m1, __int_as_float(__builtin_amdgcn_update_dpp(mi, mi, 0xB1, 0xf, 0xf, false)));  // lane ^ 1
+                        if (lane_ok[n] && pool_writer) p[o_pool_s[n]] = m2;
+                    });
+                });
+            }
             if constexpr (SCAT) {
                 const unsigned W2 = 2u * unsigned(W);
                 static_for<0, 4>([&](auto jc) {
@@ -1073,7 +1126,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     const bool full_tile = co0 + C::COUT_T <= a.cout;
     const bool has_raw = a.out_raw != nullptr, has_res = a.res1 != nullptr, has_pool = a.pool_out != nullptr;
     const bool scat = a.up_out == 1 && a.skip != nullptr && a.out != nullptr;
-    const bool fast_ok = full_tile && !C::SPLITK && (a.out || has_pool) && (!a.up_out || scat) && (!a.skip || scat) && (CAN_POOL || !has_pool);
+    const bool fast_ok = full_tile && !C::SPLITK && (a.out || has_pool) && (!a.up_out || scat) && (!a.skip || scat) && (CAN_POOL || POOLS || !has_pool);
     const int par = a.post_scale ? (a.bias ? 2 : -1) : (a.bias ? 1 : 0);
     const int pool_mode = has_pool ? (a.out ? 1 : 2) : 0;
     const int res_mode = has_res ? (a.res2 ? 2 : 1) : 0;

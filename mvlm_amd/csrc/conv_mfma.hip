@@ -192,7 +192,7 @@ bool mvlm_conv_can_pool(const mvlm_ctx* ctx, const ConvArgs& a_in) {
 #define X(id, name, ...)                                                                                   \
     case id: {                                                                                             \
         using V = __VA_ARGS__;                                                                             \
-        return !V::SPLITK && !V::TAIL16 && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0;                  \
+        return V::CAN_POOL_ANY;                                                                            \
     }
         MVLM_CONV_VARIANTS(X)
 #undef X
@@ -205,7 +205,7 @@ bool mvlm_conv_variant_can_pool(int v) {
 #define X(id, name, ...)                                                                                   \
     case id: {                                                                                             \
         using V = __VA_ARGS__;                                                                             \
-        return !V::SPLITK && !V::TAIL16 && V::TW == 32 && V::NIMG == 1 && V::NT % 2 == 0;                  \
+        return V::CAN_POOL_ANY;                                                                            \
     }
         MVLM_CONV_VARIANTS(X)
 #undef X

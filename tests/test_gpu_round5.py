@@ -402,3 +402,47 @@ def test_opt_in_precisions_at_the_bench_size_against_the_oracle(precision, allow
     same, diff, worst = compare_with_the_oracle_landmark_by_landmark(got, gmax, inter, mesh, pipe.estimator_3d, seed=1)
     assert int(diff.sum()) <= allowed, f"{int(diff.sum())} of {diff.size} argmax planes differ from the oracle"
     assert same.mean() > 0.7 and worst < 1e-3, (same.mean(), worst)
+
+
+# --------------------------------------------------------------------------------------
+# F.max_pool2d (paulsenpredictor.py:308-328, :411) in the epilogues of the narrow and the split-K tiles of small batches
+def _pool_kernel_launches(pred, imgs):
+    import ctypes as C
+
+    ctx = pred.ctx
+    ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 1))
+    try:
+        pred.predict_device(imgs)
+        cap = 512
+        slot, var = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+        fl, ms = (C.c_double * cap)(), (C.c_float * cap)()
+        n = ctx.lib.mvlm_cnn_get_profile(ctx.handle, slot, var, fl, ms, cap)
+    finally:
+        ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0))
+    return sum(1 for i in range(n) if slot[i] < 0)
+
+
+@pytest.mark.parametrize("family,mode,n_views,pairing", [("dtu3d", "RGB", 1, 1), ("dtu3d", "geometry+depth", 12, 1), ("bu3dfe", "RGB+depth", 8, 1),
+                                                         ("dtu3d", "RGB", 3, 2), ("bu3dfe", "depth", 5, 0), ("dtu3d", "RGB+depth", 24, 1)])
+def test_fused_pooling_equals_the_pool_kernel(monkeypatch, family, mode, n_views, pairing):
+    """Small batches run the hourglass levels below 128x128 on 16- / 8- / 4-pixel-wide and split-K tiles.  Round 5: those tiles
+    emit the 2x2-max-pooled tensor from their epilogues too (partner lanes l ^ TW and l ^ 1), so the separate pool launches
+    disappear - and every result is bit for bit what the pass with the pool kernel behind each block gives."""
+    from conftest import seeded_images
+    from mvlm_amd import prediction
+
+    cls = {"dtu3d": prediction.DTU3DPredictor, "bu3dfe": prediction.BU3DFEPredictor}[family]
+    pred = cls(image_mode=mode, weights="synthetic:9", verbose=False)
+    imgs = torch.from_numpy(seeded_images(70 + n_views, n_views)).cuda()
+    pred.set_execution(graphs=False, pairing=pairing)
+    monkeypatch.setenv("MVLM_POOL_KERNEL_ONLY", "1")
+    want = pred.predict_device(imgs).clone()
+    want_heat = pred.heatmaps_device(imgs[:2]).clone()
+    n_kernel = _pool_kernel_launches(pred, imgs)
+    monkeypatch.delenv("MVLM_POOL_KERNEL_ONLY")
+    got = pred.predict_device(imgs).clone()
+    assert torch.equal(got, want)
+    assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
+    n_fused = _pool_kernel_launches(pred, imgs)
+    assert n_kernel == 11 and n_fused == 0, (n_kernel, n_fused)   # 2 in the stem, 4 per hourglass, conv7's
+    pred.set_execution(graphs=True, pairing=1)
