@@ -406,7 +406,6 @@ struct Exec {
 
     // would conv `slot` on this input run a kernel variant that can also emit the pooled tensor?
     bool pool_fusable(int slot, const Tensor& x, ConvArgs a, int S) {
-        if (st.fast) return false;  // the split-operand kernels have no pooled output: the pool kernel follows the block
         if (no_pool_fusion) return false;
         const int32_t* r = d(slot);
         a.cin = r[1];
@@ -417,6 +416,7 @@ struct Exec {
         a.B = B;
         a.H = a.W = S;
         (void)x;
+        if (runs_fast(slot, a)) return !(S & 1);  // the split-operand kernels pool in their epilogues too (round 5)
         return mvlm_conv_can_pool(ctx, a);
     }
 

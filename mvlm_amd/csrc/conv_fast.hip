@@ -117,6 +117,7 @@ struct FastCfg {
     static_assert(TAP_MFMAS == (NS == 3 ? 24 : 12) || (NS == 2 && TAP_MFMAS == 6),
                   "the staging schedules below are written for 24 (bf16x3) / 12 (f16x2) / 6 (f16x2, 32 channels) MFMAs per tap");
     static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
+    static_assert(NT % 2 == 0, "the pooled output pairs the row segments of a wave");
 };
 
 // GEN: the rarely needed parts (input channels that do not fill the last chunk, a second residual) are compiled in
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                         ps = a.post_scale[co];
                         pt = a.post_shift[co];
                     }
+                    float vf[NT];
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         if constexpr (NS == 2) finite_chk = fmaf(acc[m][n][r], 0.f, finite_chk);  // stays 0 unless inf / NaN
@@ -522,12 +524,27 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                         if constexpr (RES2) {
                             if (res2) v += resv2[r][n];
                         }
+                        vf[n] = v;
                         if constexpr (SCAT) {
                             float* const po = a.out + (size_t(b0) * a.out_ctot + a.out_coff + co) * (4 * size_t(HW)) + pix2[n];
                             *reinterpret_cast<f32x2*>(po) = (f32x2){v + sk0[q][n].x, v + sk0[q][n].y};
                             *reinterpret_cast<f32x2*>(po + W2) = (f32x2){v + sk1[q][n].x, v + sk1[q][n].y};
                         } else {
-                            if (!RAW || a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
+                            if (a.out) a.out[(size_t(b0) * a.out_ctot + a.out_coff + co) * HW + pix[n]] = v;
+                        }
+                    }
+                    if constexpr (!SCAT) {
+                        // F.max_pool2d(y, 2, 2) from the epilogue (round 5; the exact tiles always had it): the rows of a pair are
+                        // two row segments of this lane (n, n + 1), the columns two neighbouring lanes
+                        if (a.pool_out) {  // (wave-uniform)
+                            float* const pp = a.pool_out + (size_t(b0) * a.pool_ctot + a.pool_coff + co) * (HW / 4);
+#pragma unroll
+                            for (int n = 0; n < NT; n += 2) {
+                                const float v2 = fmaxf(vf[n], vf[n + 1]);
+                                const int vi = __float_as_int(v2);
+                                const float other = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xf, 0xf, false));  // lane ^ 1
+                                if ((l31 & 1) == 0) pp[unsigned((y0 + NT * wn + n) >> 1) * unsigned(W >> 1) + unsigned((x0 + l31) >> 1)] = fmaxf(v2, other);
+                            }
                         }
                     }
                 }
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
         epilogue(T_{}, T_{}, std::integral_constant<int, 0>{}, T_{});   // conv1 / conv2 of a level's last block on the way up
     else if (scat)
         epilogue(F_{}, T_{}, std::integral_constant<int, 0>{}, T_{});   // ... its conv3
-    else if (has_raw && has_res && plain && a.out)
+    else if (has_raw && has_res && plain)
         epilogue(T_{}, T_{}, std::integral_constant<int, 0>{}, F_{});   // residual block conv1 / conv2
     else if (!has_raw && has_res && plain)
         epilogue(F_{}, T_{}, std::integral_constant<int, 0>{}, F_{});   // residual block conv3
@@ -604,7 +621,9 @@ bool mvlm_conv_fast_ok(const ConvArgs& a, int splits) {
     // the step 59.2 -> 55.0 ms); on bf16x3 the same twelve launches bought 3 % and their different rounding flipped one of
     // 8 064 near-tied argmax planes of the bench's random-weight network, so that form keeps round 2's layer set
     const bool scatter = splits == 2 && a.up_out == 1 && a.skip && a.out && a.res1 && !a.res2 && !a.bias && !a.post_scale;
-    return a.W % FT_TW == 0 && a.H % rows == 0 && !a.up_in && ((!a.up_out && !a.skip) || scatter) && !a.amax_val && !a.pool_out && (a.out || a.out_raw);
+    // (pooled output, round 5: with the plain NCHW forms; every tile holds an even number of rows per wave)
+    return a.W % FT_TW == 0 && a.H % rows == 0 && !a.up_in && ((!a.up_out && !a.skip) || scatter) && !a.amax_val && (!a.pool_out || !a.up_out) &&
+           (a.out || a.out_raw || a.pool_out);
 }
 
 // splits: 3 = bf16x3 ("fast"), 2 = f16x2 ("fast16": the weights carry the power-of-two scale 1 / unscale)

@@ -446,3 +446,29 @@ def test_fused_pooling_equals_the_pool_kernel(monkeypatch, family, mode, n_views
     n_fused = _pool_kernel_launches(pred, imgs)
     assert n_kernel == 11 and n_fused == 0, (n_kernel, n_fused)   # 2 in the stem, 4 per hourglass, conv7's
     pred.set_execution(graphs=True, pairing=1)
+
+
+@pytest.mark.parametrize("precision", ["fast16", "fast"])
+def test_split_operand_kernels_pool_in_their_epilogues(monkeypatch, precision):
+    """precision="fast16" / "fast": the blocks whose pooled copy is wanted (stem, conv4, the first block of every hourglass
+    level, conv7) used to write their full-resolution sum and run the pool kernel behind it - 1.6 ms of a 54-ms step at 96
+    views.  The split-operand kernels now emit the pooled tensor themselves; the pass equals the one with the pool kernel
+    bit for bit."""
+    from conftest import seeded_images
+    from mvlm_amd.prediction import BU3DFEPredictor
+
+    pred = BU3DFEPredictor(image_mode="RGB+depth", weights="synthetic:9", verbose=False, precision=precision)
+    imgs = torch.from_numpy(seeded_images(81, 8)).cuda()
+    pred.set_execution(graphs=False)
+    monkeypatch.setenv("MVLM_POOL_KERNEL_ONLY", "1")
+    want = pred.predict_device(imgs).clone()
+    want_heat = pred.heatmaps_device(imgs[:2]).clone()
+    n_kernel = _pool_kernel_launches(pred, imgs)
+    monkeypatch.delenv("MVLM_POOL_KERNEL_ONLY")
+    got = pred.predict_device(imgs).clone()
+    assert pred.precision == precision and not pred.fast16_overflowed()
+    assert torch.equal(got, want) and torch.isfinite(got).all()
+    assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
+    n_fused = _pool_kernel_launches(pred, imgs)
+    assert n_kernel == 11 and n_fused == 0, (n_kernel, n_fused)
+    pred.set_execution(graphs=True)
