@@ -444,7 +444,9 @@ def test_fused_pooling_equals_the_pool_kernel(monkeypatch, family, mode, n_views
     assert torch.equal(got, want)
     assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
     n_fused = _pool_kernel_launches(pred, imgs)
-    assert n_kernel == 11 and n_fused == 0, (n_kernel, n_fused)   # 2 in the stem, 4 per hourglass, conv7's
+    # 2 in the stem, 4 per hourglass, conv7's; what may remain: a 32x32 level served by the one-row split-K tiles (t1x32: the
+    # rows of a 2x2 block lie in two workgroups) - one block per hourglass at some batch sizes
+    assert n_kernel == 11 and n_fused <= 2, (n_kernel, n_fused)
     pred.set_execution(graphs=True, pairing=1)
 
 
