@@ -227,24 +227,11 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
         static_for<0, X_ITERS>([&](auto ic) { load_x_item(ic, chunk); });
     };
     // BatchNorm + ReLU, split: channels 2 jp and 2 jp + 1 of item i -> one u32 per split
-    // the BatchNorm parameters of a channel pair come out of LDS one slot BEFORE the pair is converted (round 5: read at the
-    // point of use, every pair stalled its wave for an LDS round trip - and with it, behind the in-order counter, for the
-    // operand fragments requested ahead)
-    f32x4 bnreg = {0.f, 0.f, 0.f, 0.f};
-    auto load_bn = [&](auto ic, int jp, int chunk) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (i < X_ITERS) {
-            bnreg = *reinterpret_cast<const f32x4*>(sbn + chunk * 32 + xbn[i] + 4 * jp);  // scale, scale, shift, shift of channels c, c + 1
-            // LDS reads stay on this side (everything else may cross): left alone, the scheduler sinks the read to its use
-            __builtin_amdgcn_sched_barrier(0x27F);
-        }
-    };
     auto convert_pair = [&](auto ic, auto jc, int chunk) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, jp = decltype(jc)::value;
         if constexpr (i < X_ITERS) {
             const int c = chunk * 16 + ((xbn[i] & 16) >> 1) + 2 * jp;  // (xbn = 16 kh [+ 512])
-            const f32x4 bn = bnreg;
-            if constexpr (jp < 3) load_bn(ic, jp + 1, chunk);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(sbn + chunk * 32 + xbn[i] + 4 * jp);  // scale, scale, shift, shift of channels c, c + 1
             float v0 = fmaxf(fmaf(xv[i][2 * jp], bn.x, bn.z), relu_floor);
             float v1 = fmaxf(fmaf(xv[i][2 * jp + 1], bn.y, bn.w), relu_floor);
             if (partial_cin) {  // channels past cin
@@ -282,7 +269,6 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     };
     // all of item i at once (prologue)
     auto stage_item = [&](auto ic, int chunk) __attribute__((always_inline)) {
-        load_bn(ic, 0, chunk);
         static_for<0, 4>([&](auto jc) { convert_pair(ic, jc, chunk); });
         static_for<0, NS>([&](auto sc) { store_x(ic, sc, chunk); });
     };
@@ -325,29 +311,6 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
     static_for<1, X_ITERS>([&](auto ic) { load_x_item(ic, 1); });
     __syncthreads();
 
-    // Operand fragments one tap AHEAD (round 5, the f16x2 tiles with room for a second set of fragment registers): left to
-    // the compiler, a tap's ds_read_b128s were issued right in front of the MFMAs that need them - every group of 4-8 MFMAs
-    // opened with the matrix pipe waiting ~100 cycles for LDS (rocprofv3: 0.59 MFMA busy; the two waves of a SIMD run in step
-    // behind the unit barrier, so they wait together).  Now tap t + 1's fragments are requested behind the FIRST MFMA of tap
-    // t and are in registers when their tap starts.  Across a unit boundary: the barrier moves up in front of the unit's last
-    // MFMAs (every LDS read of the unit is complete by then - tap 2's fragments were fetched during tap 1 - and every LDS
-    // write for the next unit has been issued), the next unit's first fragments are requested right behind it, and the
-    // remaining MFMAs cover their latency.
-    constexpr bool PREF = NS == 2 && (COUT_T == 128 || COUT_T == 32);
-    frag_t afc[MT][NS], bfc[NT][NS];
-    auto read_frags = [&](const unsigned char* ws, const unsigned char* xs, int row, int t, frag_t (&fa)[MT][NS], frag_t (&fb)[NT][NS])
-                          __attribute__((always_inline)) {
-        const int poff = (row * FT_PW + t) * 16;
-#pragma unroll
-        for (int sp = 0; sp < NS; ++sp) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) fa[m][sp] = *reinterpret_cast<const frag_t*>(ws + ((t * 2 * NS + sp) * COUT_T) * 16 + aoff[m]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) fb[n][sp] = *reinterpret_cast<const frag_t*>(xs + sp * NPIX * 16 + boff[n] + poff);
-        }
-    };
-    if constexpr (PREF) read_frags(sW, sX, 0, 0, afc, bfc);  // unit 0, tap 0 (stages 0: the prologue's barrier is behind us)
-
     // One unit = (chunk, tap row ROW): 3 taps x 24 (12) MFMAs per wave.  The staging of what comes next is cut into
     // micro-operations placed BETWEEN the MFMAs (slot q = 24 tap + index): the matrix pipe holds a wave's vector issue
     // for 8 of an MFMA's 32 cycles, the rest is where BatchNorm / split / LDS writes of the next stage run.
@@ -364,22 +327,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
         const unsigned char* const xs = sX + (chunk & 1) * X_BYTES;
         const unsigned char* const ws = sW + (u & 1) * W_BYTES;
         frag_t af[MT][NS], bf[NT][NS];
-        // PREF: slot behind which the unit's barrier and the next unit's first fragment reads go (every LDS write of the
-        // staging schedule sits in an earlier slot)
-        constexpr int BARQ = 3 * TAPM - (TAPM == 6 ? 2 : 4);
         static_for<0, 3>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int poff = (ROW * FT_PW + t) * 16;  // tap (ROW, t): dy = ROW, dx = t in the haloed tile
-            frag_t afn[MT][NS], bfn[NT][NS];  // PREF: the fragments of the tap after this one (unused otherwise)
-            if constexpr (PREF) {
-#pragma unroll
-                for (int sp = 0; sp < NS; ++sp) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) af[m][sp] = afc[m][sp];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) bf[n][sp] = bfc[n][sp];
-                }
-            } else {
 #if defined(MVLM_FAST_ABLATE_ONE_TAP)  // timing experiment only: fragments are read for the first tap of a unit only
             if constexpr (t == 0)
 #endif
@@ -392,31 +342,11 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 for (int n = 0; n < NT; ++n)
                     bf[n][sp] = *reinterpret_cast<const frag_t*>(xs + sp * NPIX * 16 + boff[n] + poff);
             }
-            }
             // the cross terms, smallest first (Split<NS>)
             static_for<0, TAPM>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, q = TAPM * t + i;
                 constexpr int p = i / (MT * NT), mn = i % (MT * NT), m = mn / NT, n = mn % NT;
-                if constexpr (PREF && t == 2 && q == BARQ) {
-                    // the unit's barrier, in front of its last MFMAs; then the first fragments of the next unit: W stage
-                    // (u + 1) & 1, tap row ROW + 1 of this chunk's X stage or row 0 of the next chunk's
-                    __builtin_amdgcn_sched_barrier(0);
-                    __syncthreads();
-                    read_frags(sW + ((u + 1) & 1) * W_BYTES, ROW == 2 ? sX + ((chunk + 1) & 1) * X_BYTES : xs, ROW == 2 ? 0 : ROW + 1, 0, afn, bfn);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#if defined(MVLM_FAST_EXP_SETPRIO)  // experiment: the wave at an MFMA wins the SIMD's issue over its neighbour's side work
-                __builtin_amdgcn_s_setprio(1);
-#endif
                 acc[m][n] = SP::mfma(af[m][SP::WS[p]], bf[n][SP::XS[p]], acc[m][n]);
-#if defined(MVLM_FAST_EXP_SETPRIO)
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                if constexpr (PREF && t < 2 && i == 0) {  // tap t + 1's fragments, behind this tap's first MFMA
-                    __builtin_amdgcn_sched_barrier(0);
-                    read_frags(ws, xs, ROW, t + 1, afn, bfn);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 // ---- side work of slot q ----
 #if defined(MVLM_FAST_ABLATE_NO_STAGING)  // timing experiment only: wrong results
                 if constexpr (q < 0) {
@@ -451,12 +381,8 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 constexpr int S1 = T6 ? 5 : (NS == 3 ? 18 : 9), S1S = T6 ? 1 : (NS == 3 ? 2 : 1);
                 constexpr int C2 = T6 ? 9 : (NS == 3 ? 28 : 18), C2S = T6 ? 1 : (NS == 3 ? 4 : 2);    // ROW 2, item 2
                 constexpr int S2 = T6 ? 14 : (NS == 3 ? 60 : 28), S2S = T6 ? 1 : (NS == 3 ? 4 : 2);
-                if constexpr (ROW == 1 && q == C0 - 1) load_bn(std::integral_constant<int, 0>{}, 0, chunk + 1);
-                if constexpr (ROW == 2 && X_ITERS >= 2 && q == C1 - 1) load_bn(std::integral_constant<int, 1>{}, 0, chunk + 1);
-                if constexpr (ROW == 2 && X_ITERS >= 3 && q == C2 - 1) load_bn(std::integral_constant<int, 2>{}, 0, chunk + 1);
                 if constexpr (ROW == 1) {
                     if constexpr (q >= C0 && q < C0 + 4 * C0S && (q - C0) % C0S == 0) {
-                        __builtin_amdgcn_sched_barrier(0);  // the pair's arithmetic stays behind this slot's MFMA (its BatchNorm parameters were requested a slot ago)
                         convert_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (q - C0) / C0S>{}, chunk + 1);
                     }
                     if constexpr (q == (C0 + 3 * C0S + 1 > XL ? C0 + 3 * C0S + 1 : XL)) {
@@ -470,7 +396,6 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 }
                 if constexpr (ROW == 2 && X_ITERS >= 2) {
                     if constexpr (q >= C1 && q < C1 + 4 * C1S && (q - C1) % C1S == 0) {
-                        __builtin_amdgcn_sched_barrier(0);  // the pair's arithmetic stays behind this slot's MFMA (its BatchNorm parameters were requested a slot ago)
                         convert_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, (q - C1) / C1S>{}, chunk + 1);
                     }
                     if constexpr (q == (C1 + 3 * C1S + 1 > XL ? C1 + 3 * C1S + 1 : XL)) {
@@ -484,7 +409,6 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 }
                 if constexpr (ROW == 2 && X_ITERS >= 3) {
                     if constexpr (q >= C2 && q < C2 + 4 * C2S && (q - C2) % C2S == 0) {
-                        __builtin_amdgcn_sched_barrier(0);  // the pair's arithmetic stays behind this slot's MFMA (its BatchNorm parameters were requested a slot ago)
                         convert_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, (q - C2) / C2S>{}, chunk + 1);
                     }
                     if constexpr (q == (C2 + 3 * C2S + 1 > XL + 1 ? C2 + 3 * C2S + 1 : XL + 1)) {
@@ -498,18 +422,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArg
                 }
                 }
             });
-            if constexpr (PREF) {
-#pragma unroll
-                for (int sp = 0; sp < NS; ++sp) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) afc[m][sp] = afn[m][sp];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) bfc[n][sp] = bfn[n][sp];
-                }
-            }
         });
 #if !defined(MVLM_FAST_ABLATE_NO_BARRIER)  // timing experiment only
-        if constexpr (!PREF) __syncthreads();
+        __syncthreads();
 #endif
     };
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
