@@ -55,6 +55,7 @@ struct Exec {
     // MVLM_POOL_KERNEL_ONLY=1 (tests; launch-by-launch passes only - a captured graph keeps what it was captured with): every
     // max_pool2d as its own launch behind the block, the form the fused epilogues are compared with bit for bit
     const bool no_pool_fusion = [] { const char* e = getenv("MVLM_POOL_KERNEL_ONLY"); return e && e[0] == '1'; }();
+    const bool scatter_only = [] { const char* e = getenv("MVLM_SCATTER_ONLY"); return e && e[0] == '1'; }();
 
     Exec(mvlm_ctx* c, int batch, void* w, size_t wb, bool d) : ctx(c), st(c->cnn), B(batch), ws((char*)w), ws_bytes(wb), dry(d) {}
 
@@ -420,11 +421,34 @@ struct Exec {
         return mvlm_conv_can_pool(ctx, a);
     }
 
+    // can the layer that consumes a hourglass's output (conv5 / conv9: 256 -> 256 @ 128x128) add the top level's low3 on its
+    // load?  Exact precision only (the split-operand kernels have no second input), where the dispatcher's measured choice for
+    // that layer is the tile that has the form; MVLM_SCATTER_ONLY=1 (tests) keeps the producer-side scatter everywhere.
+    bool consumer_side_add(int slot) {
+        if (st.fast || scatter_only) return false;
+        ConvArgs a;
+        Tensor x;
+        x.C = d(slot)[1];
+        x.S = 128;
+        const int saved = rc;
+        if (fill(slot, x, a, 128)) {
+            rc = saved;
+            return false;
+        }
+        a.out = reinterpret_cast<float*>(ws);  // (any non-null pointer: the question is about shapes)
+        a.out_ctot = a.cout;
+        return mvlm_conv_in2_ok(ctx, a);
+    }
+
     // HourGlassModule.forward (paulsenpredictor.py:301-361).  rb0 = index of this
     // hourglass's rb1 in the canonical residual-block order.  Consumes nothing; the caller
     // releases x.
     // x_pooled = max_pool2d(x) (the producer of x emits it from its epilogue where it can).
-    Tensor hourglass(int rb0, const Tensor& x, const Tensor& x_pooled) {
+    // low_out != nullptr (round 5): the level's last block on the way up (rb20) writes its plain output [256 @ 64x64] to
+    // *low_out instead of scattering every value into its 2x2 block of up1; the layer that reads the hourglass's output
+    // (conv5 / conv9) then adds it on its load (ConvArgs::in2) - the same sums, bit for bit, without the producer rewriting
+    // four times its tile.
+    Tensor hourglass(int rb0, const Tensor& x, const Tensor& x_pooled, Tensor* low_out = nullptr) {
         auto R = [&](int i) { return rb0 + i - 1; };
         // Small batches: the 32x32 .. 4x4 levels are a chain of ~60 short, latency-bound launches on few
         // workgroups.  They only depend on low1's pooled copy, and the 128x128 / 64x64 skip blocks (up1, up11)
@@ -496,7 +520,10 @@ struct Exec {
         release(low23);
         Tensor low24 = rb(R(19), up11, nullptr);
         release(up11);
-        rb(R(20), low24, &up1);  // add5
+        if (low_out)
+            *low_out = rb(R(20), low24, nullptr);  // low3 of the top level; add5 happens on the consumer's load
+        else
+            rb(R(20), low24, &up1);  // add5
         release(low24);
         return up1;
     }
@@ -524,16 +551,23 @@ struct Exec {
         Tensor r3p;
         Tensor r3 = rb(2, a2, nullptr, &r3p);  // conv4 (+ its pooled copy for the hourglass)
         release(a2);
-        Tensor h1 = hourglass(3, r3, r3p);
+        Tensor h1_low;
+        const bool cs1 = consumer_side_add(SLOT_CONV5);
+        Tensor h1 = hourglass(3, r3, r3p, cs1 ? &h1_low : nullptr);
         release(r3p);
         Tensor ll1 = alloc(256, 128);
         {
             ConvArgs a;
             a.out = ll1.p;
             a.out_ctot = 256;
-            conv(SLOT_CONV5, h1, a, 128);  // conv5 + bn2 + relu
+            if (cs1) {
+                a.in2 = h1_low.p;
+                a.in2_ctot = h1_low.C;
+            }
+            conv(SLOT_CONV5, h1, a, 128);  // conv5 + bn2 + relu (on up1 + upsample(low3) when the add is the consumer's)
         }
         release(h1);
+        if (cs1) release(h1_low);
         Tensor x6 = alloc(NL, 128);
         {
             ConvArgs a;
@@ -563,7 +597,9 @@ struct Exec {
         release(x6);
         release(r3);
         release(ll1);
-        Tensor h2 = hourglass(23, sum, sump);
+        Tensor h2_low;
+        const bool cs2 = consumer_side_add(SLOT_CONV5 + 3);
+        Tensor h2 = hourglass(23, sum, sump, cs2 ? &h2_low : nullptr);
         release(sump);
         release(sum);
         Tensor x9 = alloc(256, 128);
@@ -571,9 +607,14 @@ struct Exec {
             ConvArgs a;
             a.out = x9.p;
             a.out_ctot = 256;
+            if (cs2) {
+                a.in2 = h2_low.p;
+                a.in2_ctot = h2_low.C;
+            }
             conv(SLOT_CONV5 + 3, h2, a, 128);  // conv9 + bn3 + relu
         }
         release(h2);
+        if (cs2) release(h2_low);
         Tensor x10 = alloc(NL, 128);
         {
             ConvArgs a;

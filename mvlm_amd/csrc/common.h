@@ -99,6 +99,12 @@ struct ConvArgs {
     int amax_par_stride = 0;
     const float* skip = nullptr;
     int skip_ctot = 0, skip_coff = 0;
+    // consumer-side "upsample x 2 + skip" (round 5; paulsenpredictor.py:334-359 seen from the layer that READS the sum): the
+    // input value is in[b][c][y][x] + in2[b][c][y >> 1][x >> 1], in2 = [B][in2_ctot][H/2][W/2] - the hourglass's last block
+    // then writes its plain output instead of scattering every value into its 2x2 block of the skip tensor.  Served by the
+    // dominant tile only (conv5 / conv9: mvlm_conv_in2_ok).
+    const float* in2 = nullptr;
+    int in2_ctot = 0;
     // split-K tiles only: input channels divided over `kparts` workgroups per output tile (set by the variant id);
     // kws = partial tiles [tile][part][16][64] f32, kcnt = one arrival counter per tile (zero between launches)
     int kparts = 1;
@@ -306,6 +312,7 @@ constexpr long MVLM_KPARTS_MAX_TILES = 2048;  // output tiles of a launch that d
 constexpr long MVLM_KPARTS_MAX_PARTS = 4096;  // tiles x parts (4 KB of partial sums each)
 int mvlm_conv_kparts_workspace(mvlm_ctx* ctx, float** ws, unsigned** cnt);
 int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out);
+bool mvlm_conv_in2_ok(const mvlm_ctx* ctx, const ConvArgs& a);  // this launch would run on the tile that can add ConvArgs::in2 on its load
 bool mvlm_conv_can_pool(const mvlm_ctx* ctx, const ConvArgs& a);  // the variant this launch would use can also emit the 2x2 max-pooled tensor
 int mvlm_conv_kind(const ConvArgs& a);
 bool mvlm_conv_variant_can_pool(int variant);

@@ -77,6 +77,8 @@ struct Cfg {
     static constexpr bool POOL32 = !SPLITK && TW == 32 && NIMG == 1 && (PIX_T / 4 / 32) % 2 == 0 && COUT_T % 32 == 0;
     static constexpr bool POOL_SMALL = TW < 32 && TRI % 2 == 0 && COUT_T % 32 == 0;
     static constexpr bool CAN_POOL_ANY = POOL32 || POOL_SMALL;
+    // the tile that also exists with a second input tensor added on the load (ConvArgs::in2): the dominant 128 x (8 x 32) tile
+    static constexpr bool HAS_IN2 = !SPLITK && COUT_T == 128 && TW == 32 && TRI == 8 && NIMG == 1 && KS == 3 && CK == 4;
     // variants that also exist as a two-problem launch (conv_pair_kernel): the tiles of the residual blocks' 3x3 convolutions
     static constexpr bool PAIRABLE = KS == 3 && COUT_T % 32 == 0 && COUT_T != 96 && !(SPLITK && PIX_T != 32);
     static_assert(SPLITK ? ((PIX_T == 32 || PIX_T == 64) && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
@@ -94,6 +96,7 @@ struct Cfg {
 template <class C>
 struct StageRegs {
     float xv[C::X_ITERS];
+    float xv2[C::X_ITERS];  // IN2 kernels only: the low-resolution tensor's value of the same element
     f32x4 wv[C::W_ITERS];
     float bn_s[C::X_ITERS], bn_t[C::X_ITERS];
 };
@@ -120,16 +123,20 @@ struct SplitKTails {
 // Issue the global load of item T for K-chunk cb.  Loads are unconditional (out-of-tile /
 // padding elements read element 0 and are zeroed at write time): a branch around a load makes
 // the compiler wait for each one separately.
-template <class C, int T, bool BN_FROM_GLOBAL = false>
+template <class C, int T, bool BN_FROM_GLOBAL = false, bool IN2 = false>
 __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, unsigned HWin, const float* sbn,
                                            const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
-                                           StageRegs<C>& r, float* st_dst) {
+                                           StageRegs<C>& r, float* st_dst, const unsigned (&goff2)[C::X_ITERS]) {
     if constexpr (T < C::X_ITERS) {
         const int c = cb + (tid + T * 256) / C::PLANE;
         const bool ok = goff[T] != INVALID_OFF && c < a.cin;
         // wave-uniform base; one unconditional load per lane (masked lanes read a valid element)
         const float* const base = a.in + size_t(cb < a.cin ? cb : 0) * HWin;
         r.xv[T] = base[ok ? goff[T] : 0u];
+        if constexpr (IN2) {  // the same element of the half-resolution tensor (four staged elements share one: L1 / L2 hits)
+            const float* const base2 = a.in2 + size_t(cb < a.cin ? cb : 0) * (HWin >> 2);
+            r.xv2[T] = base2[ok ? goff2[T] : 0u];
+        }
         if (a.pre_scale != nullptr) {  // this element's BatchNorm scale / shift from the LDS copy
             const int cc = c < a.cin_pad ? c : 0;
             if constexpr (BN_FROM_GLOBAL) {  // first chunk: the LDS copy is still being filled
@@ -148,7 +155,7 @@ __device__ __forceinline__ void issue_item(const ConvArgs& a, int cb, int tid, u
 }
 
 // BatchNorm + ReLU (pre-activation block), zero padding AFTER the activation, then the LDS write
-template <class C, int T>
+template <class C, int T, bool IN2 = false>
 __device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, float* st,
                                            const unsigned (&goff)[C::X_ITERS], const StageRegs<C>& r) {
     if constexpr (T < C::X_ITERS) {
@@ -156,6 +163,7 @@ __device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, f
         const int c = cb + e / C::PLANE;
         const bool ok = goff[T] != INVALID_OFF && c < a.cin;
         float v = r.xv[T];
+        if constexpr (IN2) v += r.xv2[T];  // skip + upsampled low: the sum the scatter form leaves in the skip tensor, bit for bit
         if (a.pre_scale != nullptr) v = fmaxf(fmaf(v, r.bn_s[T], r.bn_t[T]), 0.f);
         v = ok ? v : 0.f;
         if (e < C::XT) st[e] = v;
@@ -174,12 +182,13 @@ __device__ __forceinline__ void write_item(const ConvArgs& a, int cb, int tid, f
 // TR: the accumulators hold the TRANSPOSED tile (rows = pixels, columns = output channels): the operands of
 // every MFMA are swapped, nothing else changes.  The fused-argmax launches use it: a lane then owns ONE output
 // channel and 16 pixels per tile, so the per-channel maximum is a chain of in-register compares.
-template <class C, bool STAGE_NEXT, bool TR = false>
+template <class C, bool STAGE_NEXT, bool TR = false, bool IN2 = false>
 __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st, float* st_next, int cb_next, int tid,
                                               unsigned HWin, const float* sbn, int woff, const int (&pixoff)[C::NT],
                                               const unsigned (&goff)[C::X_ITERS], const unsigned (&woff_g)[C::W_ITERS],
                                               StageRegs<C>& r, f32x16 (&acc)[C::MT][C::NT], int woff16,
-                                              const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16], Strip4& s4) {
+                                              const int (&pixoff16)[C::NT16], f32x4 (&acc16)[C::NT16], Strip4& s4,
+                                              const unsigned (&goff2)[C::X_ITERS]) {
     constexpr int T_TOT = C::X_ITERS + C::W_ITERS;
     // staging schedule of the next chunk: loads issued over the first ISSUE_SPAN k-steps, LDS writes over the last WRITE_SPAN
 #if !defined(MVLM_STAGE_ISSUE_DIV)
@@ -253,10 +262,10 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
             static_for<0, T_TOT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
 #if !defined(MVLM_ABLATE_NO_LOADS)
-                if constexpr ((t * ISSUE_SPAN) / T_TOT == ks) issue_item<C, t>(a, cb_next, tid, HWin, sbn, goff, woff_g, r, st_next);
+                if constexpr ((t * ISSUE_SPAN) / T_TOT == ks) issue_item<C, t, false, IN2>(a, cb_next, tid, HWin, sbn, goff, woff_g, r, st_next, goff2);
 #endif
 #if !defined(MVLM_ABLATE_NO_WRITES)
-                if constexpr (WRITE_START + (t * WRITE_SPAN) / T_TOT == ks) write_item<C, t>(a, cb_next, tid, st_next, goff, r);
+                if constexpr (WRITE_START + (t * WRITE_SPAN) / T_TOT == ks) write_item<C, t, IN2>(a, cb_next, tid, st_next, goff, r);
 #endif
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -297,7 +306,7 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
 // conv_tile is the whole workgroup program; the kernels below only say which problem a workgroup belongs to:
 // conv_mfma_kernel = one convolution per launch (block `bid` of `nblk`), conv_pair_kernel = two independent convolutions
 // of the same tile configuration in one grid.
-template <class C, bool AMAX>
+template <class C, bool AMAX, bool IN2 = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_x, const int tiles_y, const int cout_tiles,
                                           const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -358,6 +367,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
 
     // ---- per-thread staging plan for the input tile (fixed across K-chunks) ----------
     unsigned goff[C::X_ITERS];
+    unsigned goff2[C::X_ITERS];  // IN2: offsets into the half-resolution tensor
 #pragma unroll
     for (int i = 0; i < C::X_ITERS; ++i) {
         const int e = tid + i * 256;
@@ -371,6 +381,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
         const bool ok = (e < C::XT) && y >= 0 && y < H && x >= 0 && x < W && b < a.B;
         const int ys = a.up_in ? (y >> 1) : y, xs = a.up_in ? (x >> 1) : x;
         goff[i] = ok ? (unsigned(b * a.in_ctot + a.in_coff + c) * HWin + unsigned(ys * Win + xs)) : INVALID_OFF;
+        goff2[i] = (IN2 && ok) ? (unsigned(b * a.in2_ctot + c) * (HWin >> 2) + unsigned((ys >> 1) * (Win >> 1) + (xs >> 1))) : 0u;
     }
     // weight slice: float4 index f -> (tap, c, cout4); the source offset is chunk-invariant
     // apart from the channel base
@@ -473,14 +484,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
             }
         }
     }
-    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true>(a, cb0, tid, HWin, sbn, goff, woff_g, regs, smem); });
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true, IN2>(a, cb0, tid, HWin, sbn, goff, woff_g, regs, smem, goff2); });
     if (a.pre_scale != nullptr) {
         for (int i = tid; i < a.cin_pad; i += 256) {
             sbn[i] = a.pre_scale[i];
             sbn[C::BN_MAXC + i] = a.pre_shift[i];
         }
     }
-    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value>(a, cb0, tid, smem, goff, regs); });
+    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value, IN2>(a, cb0, tid, smem, goff, regs); });
     __syncthreads();
 
 #if defined(MVLM_CONV_TIMING)
@@ -489,18 +500,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
     int cur = 0;
     for (int cb = cb0 + C::CK; cb < cb1; cb += C::CK) {
 #if defined(MVLM_ABLATE_NO_STAGING)  // timing experiment only: wrong results
-        compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
-                                goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4);
+        compute_chunk<C, false, AMAX, IN2>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+                                goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4, goff2);
 #else
-        compute_chunk<C, true, AMAX>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
-                               goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4);
+        compute_chunk<C, true, AMAX, IN2>(a, smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, cb, tid, HWin, sbn, woff, pixoff,
+                               goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4, goff2);
 #endif
 #if !defined(MVLM_ABLATE_NO_BARRIER)
         __syncthreads();  // next stage complete; everybody is done reading this one
 #endif
         cur ^= 1;
     }
-    compute_chunk<C, false, AMAX>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4);
+    compute_chunk<C, false, AMAX, IN2>(a, smem + cur * C::STAGE, nullptr, 0, tid, HWin, sbn, woff, pixoff, goff, woff_g, regs, acc, woff16, pixoff16, acc16, s4, goff2);
 #if defined(MVLM_CONV_TIMING)
     const long long t_epi = clock64();
 #endif
@@ -1222,10 +1233,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
 
 }
 
-template <class C, bool AMAX>
+template <class C, bool AMAX, bool IN2 = false>
 __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(const ConvArgs a_in, const int tiles_x, const int tiles_y,
                                                            const int cout_tiles) {
-    conv_tile<C, AMAX>(a_in, tiles_x, tiles_y, cout_tiles, int(blockIdx.x), int(gridDim.x));
+    conv_tile<C, AMAX, IN2>(a_in, tiles_x, tiles_y, cout_tiles, int(blockIdx.x), int(gridDim.x));
 }
 
 // Two independent convolutions in ONE grid (same tile configuration; e.g. conv j of a hourglass level's skip block and
@@ -1263,6 +1274,8 @@ int check_variant(mvlm_ctx* ctx, ConvArgs& a, ConvGrid& g) {
     const int tiles_b = (a.B + C::NIMG - 1) / C::NIMG;
     const int cout_tiles = a.cout_pad / C::COUT_T;
     MVLM_REQUIRE(ctx, a.ksize == C::KS, "conv: kernel variant built for another kernel size");
+    MVLM_REQUIRE(ctx, !a.in2 || (C::HAS_IN2 && !a.up_in && !a.amax_val && a.in_coff == 0 && a.in2_ctot >= a.cin && !(a.H & 1) && !(a.W & 1) && a.kparts <= 1),
+                 "conv: a second input tensor (upsample + skip on the load) is served by the 128-channel 8x32 tile only");
     MVLM_REQUIRE(ctx, a.W % C::TW == 0 && a.H % C::TRI == 0, "conv: spatial size not a multiple of the tile");
     MVLM_REQUIRE(ctx, !C::SPLITK || a.cin_pad % 32 == 0, "conv: split-K tiles need 32-channel chunks");
     MVLM_REQUIRE(ctx, !(C::SPLITK && C::NT > 1) || (a.kparts <= 1 && !a.amax_val), "conv: the two-column split-K tiles have no K-parts / argmax form");
@@ -1318,6 +1331,9 @@ int set_variant_attributes(mvlm_ctx* ctx, int variant_id) {
     if constexpr (C::PAIRABLE)
         MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<C>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
+    if constexpr (C::HAS_IN2)
+        MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<C, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
     ctx->conv_attr_mask |= 1ull << variant_id;
     return 0;
 }
@@ -1342,6 +1358,13 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
         } else {
             return ctx->fail("conv: fused argmax is only built for the 8x32-pixel tile variants");
         }
+    } else if (a.in2) {
+        if constexpr (C::HAS_IN2) {
+            hipLaunchKernelGGL((conv_mfma_kernel<C, false, true>), dim3((unsigned)g.nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
+                               g.tiles_x, g.tiles_y, g.cout_tiles);
+        } else {
+            return ctx->fail("conv: this kernel variant has no second-input form");
+        }
     } else {
         hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)g.nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
                            g.tiles_x, g.tiles_y, g.cout_tiles);
@@ -1362,7 +1385,7 @@ int launch_variant_pair(mvlm_ctx* ctx, const ConvArgs& a0, const ConvArgs& a1, i
         ConvGrid g[2];
         for (int i = 0; i < 2; ++i) {
             ConvArgs& a = p.a[i];
-            MVLM_REQUIRE(ctx, !a.amax_val && a.n_par == 1 && !a.timing, "conv: a paired launch takes plain convolutions");
+            MVLM_REQUIRE(ctx, !a.amax_val && a.n_par == 1 && !a.timing && !a.in2, "conv: a paired launch takes plain convolutions");
             if (check_variant<C>(ctx, a, g[i])) return 1;
         }
         if (p.a[0].kparts > 1 || p.a[1].kparts > 1) {

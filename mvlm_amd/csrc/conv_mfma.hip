@@ -181,6 +181,15 @@ const char* mvlm_conv_variant_name_impl(int v) {
     return "?";
 }
 
+// Would the dispatcher run this layer on the tile that can add a second, half-resolution input tensor on its load
+// (ConvArgs::in2: the hourglass's "upsample x 2 + skip" on the consumer's side)?  The measured choice is respected: only where
+// that tile is what the tables / rules pick anyway.
+bool mvlm_conv_in2_ok(const mvlm_ctx* ctx, const ConvArgs& a) {
+    if (a.ksize != 3 || a.up_in || a.up_out || a.amax_val || a.in_coff != 0 || (a.H & 1) || a.H != a.W) return false;
+    if (ctx && ctx->conv_force_variant != -1) return false;
+    return pick_variant(ctx, a) == 0;
+}
+
 int mvlm_conv_kind(const ConvArgs& a) { return a.up_out == 1 ? 1 : ((a.pool_out || a.pool_hint) ? 2 : 0); }
 
 bool mvlm_conv_can_pool(const mvlm_ctx* ctx, const ConvArgs& a_in) {
@@ -315,6 +324,8 @@ int mvlm_launch_conv(mvlm_ctx* ctx, const ConvArgs& a, int* variant_out) {
     // conv_force_variant (mvlm_conv_bench only): >= 0 that variant, -2 the rules without the tuned table
     const int v = ctx->conv_force_variant >= 0 ? ctx->conv_force_variant : pick_variant(ctx, a, ctx->conv_force_variant == -2);
     MVLM_REQUIRE(ctx, v >= 0, "conv: no kernel variant for this shape");
+    MVLM_REQUIRE(ctx, !a.in2 || v == 0, "conv: a second input tensor needs the 128-channel 8x32 tile (ask mvlm_conv_in2_ok first)");
+    MVLM_REQUIRE(ctx, !a.in2 || px / 4 * a.in2_ctot < lim, "conv: second input exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, !a.pool_out || mvlm_conv_variant_can_pool(v), "conv: this shape's kernel variant cannot emit the pooled tensor");
     MVLM_REQUIRE(ctx, !a.pool_out || px / 4 * a.pool_ctot < lim, "conv: pooled output exceeds 32-bit element offsets");
     MVLM_REQUIRE(ctx, a.out || a.pool_out || a.amax_val, "conv: no output requested");

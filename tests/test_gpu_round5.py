@@ -474,3 +474,32 @@ def test_split_operand_kernels_pool_in_their_epilogues(monkeypatch, precision):
     n_fused = _pool_kernel_launches(pred, imgs)
     assert n_kernel == 11 and n_fused == 0, (n_kernel, n_fused)
     pred.set_execution(graphs=True)
+
+
+# --------------------------------------------------------------------------------------
+# hourglass "upsample x 2 + skip" (paulsenpredictor.py:334-359) on the consumer's load (conv5 / conv9) instead of the producer's scatter
+@pytest.mark.parametrize("family,mode,n_views", [("bu3dfe", "RGB+depth", 8), ("dtu3d", "geometry+depth", 12), ("dtu3d", "RGB", 24), ("bu3dfe", "depth", 2)])
+def test_consumer_side_skip_add_equals_the_scatter(monkeypatch, family, mode, n_views):
+    """Round 5: the top level's last block on the way up writes its plain output and conv5 / conv9 read `up1 + upsample(low3)`
+    through a second input tensor on their staging loads (ConvArgs::in2, the 128-channel 8x32 tile) - wherever that tile is the
+    dispatcher's choice for the layer.  The sums are the ones the 2x2 scatter left in the skip tensor (a + b = b + a), so
+    maxima and heatmaps equal the scatter form's bit for bit, launch by launch and replayed."""
+    from conftest import seeded_images
+    from mvlm_amd import prediction
+
+    cls = {"dtu3d": prediction.DTU3DPredictor, "bu3dfe": prediction.BU3DFEPredictor}[family]
+    pred = cls(image_mode=mode, weights="synthetic:13", verbose=False)
+    imgs = torch.from_numpy(seeded_images(90 + n_views, n_views)).cuda()
+    pred.set_execution(graphs=False)
+    monkeypatch.setenv("MVLM_SCATTER_ONLY", "1")
+    want = pred.predict_device(imgs).clone()
+    want_heat = pred.heatmaps_device(imgs[:2]).clone()
+    monkeypatch.delenv("MVLM_SCATTER_ONLY")
+    got = pred.predict_device(imgs).clone()
+    assert torch.equal(got, want)
+    assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
+    pred.set_execution(graphs=True)
+    out = torch.empty_like(got)
+    for _ in range(3):
+        assert torch.equal(pred.predict_device(imgs, out=out), want)
+    assert pred.execution_stats()["graph_replays"] >= 1
