@@ -56,6 +56,7 @@ struct Exec {
     // max_pool2d as its own launch behind the block, the form the fused epilogues are compared with bit for bit
     const bool no_pool_fusion = [] { const char* e = getenv("MVLM_POOL_KERNEL_ONLY"); return e && e[0] == '1'; }();
     const bool scatter_only = [] { const char* e = getenv("MVLM_SCATTER_ONLY"); return e && e[0] == '1'; }();
+    const int consumer_add_max_batch = [] { const char* e = getenv("MVLM_CONSUMER_ADD_MAX_BATCH"); return e ? atoi(e) : 16; }();
 
     Exec(mvlm_ctx* c, int batch, void* w, size_t wb, bool d) : ctx(c), st(c->cnn), B(batch), ws((char*)w), ws_bytes(wb), dry(d) {}
 
@@ -424,8 +425,11 @@ struct Exec {
     // can the layer that consumes a hourglass's output (conv5 / conv9: 256 -> 256 @ 128x128) add the top level's low3 on its
     // load?  Exact precision only (the split-operand kernels have no second input), where the dispatcher's measured choice for
     // that layer is the tile that has the form; MVLM_SCATTER_ONLY=1 (tests) keeps the producer-side scatter everywhere.
+    // Measured (profiles/r05_consumer_side_add.txt): the block that stops scattering saves ~59 us per hourglass at 8 and at 12
+    // views (its epilogue is exposed in a latency-bound launch) and 244 us at 96; the second load per staged element costs the
+    // consumer 2.3 % (20 / 40 / 302 us at 8 / 12 / 96 views) - a gain up to about 16 views per device batch, a loss beyond.
     bool consumer_side_add(int slot) {
-        if (st.fast || scatter_only) return false;
+        if (st.fast || scatter_only || B > consumer_add_max_batch) return false;
         ConvArgs a;
         Tensor x;
         x.C = d(slot)[1];

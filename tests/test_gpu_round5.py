@@ -478,12 +478,29 @@ def test_split_operand_kernels_pool_in_their_epilogues(monkeypatch, precision):
 
 # --------------------------------------------------------------------------------------
 # hourglass "upsample x 2 + skip" (paulsenpredictor.py:334-359) on the consumer's load (conv5 / conv9) instead of the producer's scatter
-@pytest.mark.parametrize("family,mode,n_views", [("bu3dfe", "RGB+depth", 8), ("dtu3d", "geometry+depth", 12), ("dtu3d", "RGB", 24), ("bu3dfe", "depth", 2)])
+def _variants_by_slot(pred, imgs):
+    import ctypes as C
+
+    ctx = pred.ctx
+    ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 1))
+    try:
+        pred.predict_device(imgs)
+        cap = 512
+        slot, var = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+        fl, ms = (C.c_double * cap)(), (C.c_float * cap)()
+        n = ctx.lib.mvlm_cnn_get_profile(ctx.handle, slot, var, fl, ms, cap)
+    finally:
+        ctx.check(ctx.lib.mvlm_cnn_set_profiling(ctx.handle, 0))
+    return {int(slot[i]): int(var[i]) for i in range(n) if slot[i] >= 0}
+
+
+@pytest.mark.parametrize("family,mode,n_views", [("bu3dfe", "RGB+depth", 8), ("dtu3d", "geometry+depth", 12), ("dtu3d", "RGB", 24), ("bu3dfe", "depth", 2),
+                                                 ("bu3dfe", "RGB+depth", 40)])
 def test_consumer_side_skip_add_equals_the_scatter(monkeypatch, family, mode, n_views):
     """Round 5: the top level's last block on the way up writes its plain output and conv5 / conv9 read `up1 + upsample(low3)`
     through a second input tensor on their staging loads (ConvArgs::in2, the 128-channel 8x32 tile) - wherever that tile is the
-    dispatcher's choice for the layer.  The sums are the ones the 2x2 scatter left in the skip tensor (a + b = b + a), so
-    maxima and heatmaps equal the scatter form's bit for bit, launch by launch and replayed."""
+    dispatcher's choice for the layer.  The sums are the ones the 2x2 scatter left in the skip tensor (a + b = b + a), so with
+    the block's convolutions on the same tiles maxima and heatmaps equal the scatter form's bit for bit; replay equals eager."""
     from conftest import seeded_images
     from mvlm_amd import prediction
 
@@ -491,15 +508,28 @@ def test_consumer_side_skip_add_equals_the_scatter(monkeypatch, family, mode, n_
     pred = cls(image_mode=mode, weights="synthetic:13", verbose=False)
     imgs = torch.from_numpy(seeded_images(90 + n_views, n_views)).cuda()
     pred.set_execution(graphs=False)
+    monkeypatch.setenv("MVLM_CONSUMER_ADD_MAX_BATCH", "128")  # (the product uses the form up to 16 views per device batch: where it pays)
     monkeypatch.setenv("MVLM_SCATTER_ONLY", "1")
     want = pred.predict_device(imgs).clone()
     want_heat = pred.heatmaps_device(imgs[:2]).clone()
+    tiles_scatter = _variants_by_slot(pred, imgs)
     monkeypatch.delenv("MVLM_SCATTER_ONLY")
     got = pred.predict_device(imgs).clone()
-    assert torch.equal(got, want)
-    assert torch.equal(pred.heatmaps_device(imgs[:2]), want_heat)
+    heat = pred.heatmaps_device(imgs[:2])
+    tiles = _variants_by_slot(pred, imgs)
+    # The block that no longer scatters is another layer KIND to the dispatcher (conv_tuned_net.h is measured per kind), so its
+    # three convolutions may run on other tiles - another order of the fp32 sums, as with another device batch.  Same tiles:
+    # bit-identical; other tiles: fp32 rounding apart.
+    changed = sorted(k for k in tiles if tiles[k] != tiles_scatter.get(k))
+    assert all(k in (90, 91, 92, 170, 171, 172) for k in changed), changed   # hg1.rb20 / hg2.rb20 only
+    if not changed:
+        assert torch.equal(got, want) and torch.equal(heat, want_heat)
+    else:
+        scale = float(want_heat.abs().max())
+        assert float((heat - want_heat).abs().max()) < 2e-5 * scale
+        assert float(torch.all(got[:, :, :2] == want[:, :, :2], dim=2).float().mean()) >= 0.99
     pred.set_execution(graphs=True)
     out = torch.empty_like(got)
     for _ in range(3):
-        assert torch.equal(pred.predict_device(imgs, out=out), want)
+        assert torch.equal(pred.predict_device(imgs, out=out), got)
     assert pred.execution_stats()["graph_replays"] >= 1
