@@ -35,7 +35,6 @@
 // height of 8, plain NCHW output with optional bias / post-BN+ReLU / raw copy / one residual.  Everything else (and
 // every layer in the default "exact" precision) runs on conv_mfma_kernel.
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -54,7 +53,7 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 namespace {
 
 constexpr int FT_TW = 32, FT_PW = FT_TW + 2;
-constexpr int FT_THREADS = 512;  // the full tiles; the half tiles of the f16x2 form run 256 threads (FastCfg::THREADS)
+constexpr int FT_THREADS = 512;
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -102,35 +101,28 @@ struct Split<2> {
 
 // COUT_T output channels x (TRI rows x 32 pixels); 8 waves = WM channel groups x WN row groups (2 x 4; the 32-channel tile
 // of the f16x2 form: 1 x 8 - conv2.conv2 / conv2.conv3 / conv3.conv2 / conv3.conv3 of the stem, 4.2 ms per 96 views on exact tiles)
-// Half tiles (round 5, f16x2 only): 128 channels x 4 rows and 64 channels x 8 rows on 256 threads = 4 waves with the SAME
-// MFMA tiles per wave as the full tiles.  78 / 72 KB of LDS: TWO workgroups share a CU, so one group's prologue (first chunk's
-// round trip to memory) and epilogue (its stores) run under the other's MFMAs - with one 512-thread workgroup per CU nothing
-// overlapped them (rocprofv3: 0.59 MFMA busy).  Price: every workgroup stages the whole weight slice for half the pixels.
 template <int COUT_T, int TRI, int NS = 3>
 struct FastCfg {
-    static constexpr bool HALF = NS == 2 && ((COUT_T == 128 && TRI == 4) || (COUT_T == 64 && TRI == 8));
-    static constexpr int THREADS = HALF ? 256 : FT_THREADS;
-    static constexpr int WM = COUT_T >= 64 ? 2 : 1, WN = THREADS / 64 / WM;
+    static constexpr int WM = COUT_T >= 64 ? 2 : 1, WN = 8 / WM;
     static constexpr int MT = COUT_T / (32 * WM);        // 32-row MFMA tiles per wave (channels)
     static constexpr int NT = TRI / WN;                   // 32-pixel row segments per wave
     static constexpr int PH = TRI + 2, NPIX = FT_PW * PH;  // haloed tile
     static constexpr int X_BYTES = 2 * NS * NPIX * 16;      // [k-half][split][pixel][8 ch]
     static constexpr int W_BYTES = 3 * 2 * NS * COUT_T * 16;  // one tap row: [tap][k-half][split][cout][8 ch]
-    static constexpr int W_ITEMS = W_BYTES / 16, W_ITERS = (W_ITEMS + THREADS - 1) / THREADS;
-    static constexpr int X_ITEMS = 2 * NPIX, X_ITERS = (X_ITEMS + THREADS - 1) / THREADS;
+    static constexpr int W_ITEMS = W_BYTES / 16, W_ITERS = (W_ITEMS + FT_THREADS - 1) / FT_THREADS;
+    static constexpr int X_ITEMS = 2 * NPIX, X_ITERS = (X_ITEMS + FT_THREADS - 1) / FT_THREADS;
     static constexpr int TAP_MFMAS = Split<NS>::NTERMS * MT * NT;  // per tap and wave
     static constexpr size_t LDS = size_t(2) * X_BYTES + size_t(2) * W_BYTES + 4 * 256 * sizeof(float);  // + BatchNorm table + as many zeros
     static_assert(LDS <= 160 * 1024, "stages must fit the CU's LDS");
     static_assert(TAP_MFMAS == (NS == 3 ? 24 : 12) || (NS == 2 && TAP_MFMAS == 6),
                   "the staging schedules below are written for 24 (bf16x3) / 12 (f16x2) / 6 (f16x2, 32 channels) MFMAs per tap");
-    static_assert(X_ITERS <= 3 && W_ITERS <= 6, "staging schedule");
-    static_assert(!HALF || 2 * LDS <= 160 * 1024, "two half-tile workgroups must fit the CU's LDS");
+    static_assert(X_ITERS <= 3 && W_ITERS <= 5, "staging schedule");
     static_assert(NT % 2 == 0, "the pooled output pairs the row segments of a wave");
 };
 
 // GEN: the rarely needed parts (input channels that do not fill the last chunk, a second residual) are compiled in
 template <int COUT_T, int TRI, bool GEN, int NS>
-__global__ __launch_bounds__((FastCfg<COUT_T, TRI, NS>::THREADS), 2) void conv_split_kernel(const ConvArgs a, const unsigned short* __restrict__ wq,
+__global__ __launch_bounds__(FT_THREADS, 2) void conv_split_kernel(const ConvArgs a, const unsigned short* __restrict__ wq,
                                                                   const int tiles_x, const int tiles_y, const int cout_tiles) {
     using C = FastCfg<COUT_T, TRI, NS>;
     using SP = Split<NS>;
@@ -171,7 +163,7 @@ __global__ __launch_bounds__((FastCfg<COUT_T, TRI, NS>::THREADS), 2) void conv_s
     int xbn[X_ITERS];         // float offset of the item's BatchNorm parameters for chunk 0 in sbn
 #pragma unroll
     for (int i = 0; i < X_ITERS; ++i) {
-        const int e0 = tid + i * C::THREADS, e = e0 < X_ITEMS ? e0 : tid;
+        const int e0 = tid + i * FT_THREADS, e = e0 < X_ITEMS ? e0 : tid;
         const int kh = e / NPIX, p = e - kh * NPIX;
         const int yy = p / FT_PW, xx = p - yy * FT_PW;
         const int y = y0 + yy - 1, x = x0 + xx - 1;
@@ -185,7 +177,7 @@ __global__ __launch_bounds__((FastCfg<COUT_T, TRI, NS>::THREADS), 2) void conv_s
     int wdst[W_ITERS];
 #pragma unroll
     for (int i = 0; i < W_ITERS; ++i) {
-        const int f0 = tid + i * C::THREADS, f = f0 < W_ITEMS ? f0 : tid % W_ITEMS;  // (the 32-channel tile has fewer items than threads)
+        const int f0 = tid + i * FT_THREADS, f = f0 < W_ITEMS ? f0 : tid % W_ITEMS;  // (the 32-channel tile has fewer items than threads)
         const int seg = f / COUT_T, c = f - seg * COUT_T;
         wsrc[i] = unsigned((seg * a.cout_pad + co0 + c) * 8);
         wdst[i] = f * 16;
@@ -300,7 +292,7 @@ __global__ __launch_bounds__((FastCfg<COUT_T, TRI, NS>::THREADS), 2) void conv_s
 
     // ---- prologue: BatchNorm table, chunk 0's activations, unit 0's weights ----------------------------------------------
     // [channel pair][scale, scale, shift, shift]; without BatchNorm: 1, 0 (and no ReLU: relu_floor); then the zeros
-    for (int i = tid; i < 256; i += C::THREADS) {  // padding channels: relu(0 * 0 + 0) = 0
+    for (int i = tid; i < 256; i += FT_THREADS) {  // padding channels: relu(0 * 0 + 0) = 0
         const bool there = has_bn && i < a.cin;
         sbn[4 * (i >> 1) + (i & 1)] = there ? a.pre_scale[i] : (has_bn || i >= a.cin_pad ? 0.f : 1.f);
         sbn[4 * (i >> 1) + 2 + (i & 1)] = there ? a.pre_shift[i] : 0.f;
@@ -590,8 +582,7 @@ __global__ __launch_bounds__((FastCfg<COUT_T, TRI, NS>::THREADS), 2) void conv_s
 template <int COUT_T, int TRI, bool GEN, int NS>
 int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
     using C = FastCfg<COUT_T, TRI, NS>;
-    const int bit = C::HALF ? 46 + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0)
-                            : (COUT_T == 32 ? 54 + (GEN ? 1 : 0) : (NS == 3 ? 60 : 56) + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0));
+    const int bit = COUT_T == 32 ? 54 + (GEN ? 1 : 0) : (NS == 3 ? 60 : 56) + (COUT_T == 128 ? 0 : 1) + (GEN ? 2 : 0);
     if (!((ctx->conv_attr_mask >> bit) & 1ull)) {
         MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<COUT_T, TRI, GEN, NS>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS)));
@@ -600,7 +591,7 @@ int launch_fast(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq) {
     const int tiles_x = a.W / FT_TW, tiles_y = a.H / TRI, cout_tiles = a.cout_pad / COUT_T;
     const long nblk = long(tiles_x) * tiles_y * a.B * cout_tiles;
     MVLM_REQUIRE(ctx, nblk > 0 && nblk < (1l << 31), "conv_fast: bad grid");
-    hipLaunchKernelGGL((conv_split_kernel<COUT_T, TRI, GEN, NS>), dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, ctx->cur_stream(), a, wq,
+    hipLaunchKernelGGL((conv_split_kernel<COUT_T, TRI, GEN, NS>), dim3((unsigned)nblk), dim3(FT_THREADS), C::LDS, ctx->cur_stream(), a, wq,
                        tiles_x, tiles_y, cout_tiles);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
     return 0;
@@ -611,18 +602,6 @@ int launch_fast_ns(mvlm_ctx* ctx, const ConvArgs& a, const unsigned short* wq_de
     if constexpr (NS == 2) {
         if (a.cout_pad == 32)
             return (a.cin != a.cin_pad || a.res2) ? launch_fast<32, 16, true, 2>(ctx, a, wq_dev) : launch_fast<32, 16, false, 2>(ctx, a, wq_dev);
-    }
-    if constexpr (NS == 2) {
-        // half tiles, two workgroups per CU (MVLM_FAST16_HALF_TILES=0: the full tiles of round 4, for A/B measurements)
-        static const int half_tiles = [] { const char* e = getenv("MVLM_FAST16_HALF_TILES"); return e ? atoi(e) : 1; }();
-        if (half_tiles & 1) {
-            if (a.cout_pad % 128 == 0)
-                return (a.cin != a.cin_pad || a.res2) ? launch_fast<128, 4, true, 2>(ctx, a, wq_dev) : launch_fast<128, 4, false, 2>(ctx, a, wq_dev);
-        }
-        if (half_tiles & 2) {
-            if (a.cout_pad % 128 != 0)
-                return (a.cin != a.cin_pad || a.res2) ? launch_fast<64, 8, true, 2>(ctx, a, wq_dev) : launch_fast<64, 8, false, 2>(ctx, a, wq_dev);
-        }
     }
     if (a.cin != a.cin_pad || a.res2)
         return a.cout_pad % 128 == 0 ? launch_fast<128, 8, true, NS>(ctx, a, wq_dev) : launch_fast<64, 16, true, NS>(ctx, a, wq_dev);
