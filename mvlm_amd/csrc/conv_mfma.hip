@@ -273,6 +273,11 @@ int mvlm_conv_pair_variant(const ConvArgs& a0, const ConvArgs& a1, int mode) {
     if (it == end || it->cin_pad != key.cin_pad || it->cout_pad != key.cout_pad || it->size != key.size || it->variant < 0) return -1;
     v = it->variant;
     if (!pair_variant_serves(v & 255, a0) || !pair_variant_serves(v & 255, a1)) return -1;
+    // The table was measured without the pool kernel that follows a block whose tiles cannot emit the pooled tensor.  Since
+    // round 5 every pairable tile but the one-row split-K tiles (t1x32) pools in its epilogue; for those, keep the pair only
+    // if the single launch could not pool either (then the pool kernel runs in both forms and the comparison stands).
+    for (const ConvArgs* a : {&a0, &a1})
+        if (a->pool_hint && !mvlm_conv_variant_can_pool(v) && mvlm_conv_can_pool(nullptr, *a)) return -1;
     return v | MVLM_CONV_PAIR_FLAG;
 }
 

@@ -36,8 +36,9 @@ for v in 8 12; do
 done
 MVLM_BENCH_PER_LAYER=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > /dev/null 2> $OUT/per_layer_96.err || exit 1
 python3 tools/per_level_table.py $OUT/per_layer_96.err > $OUT/${TAG}_per_level_96views.txt
-echo "== bench.py --gpus 2 as a plain process (two gloo ranks sharing this GPU)" ; date
-MVLM_BENCH_SHARE_GPU=1 timeout -k 10 600 python3 bench.py --gpus 2 --steps 5 --warmup 2 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_rehearsal_self_launch_2ranks_one_gpu_gloo.json 2> $OUT/self_launch.err || exit 1
+echo "== bench.py --gpus 5 as a plain process (five gloo ranks sharing this GPU: the box's process guard admits six processes), configs[2] / [3] / [4] at the 8-GPU shard sizes" ; date
+timeout -k 10 900 bash tools/r5_rehearsal.sh $TAG > $OUT/rehearsal_log.txt 2>&1 || exit 1
+cp $ROOT/gpurun_out/rehearsal_$TAG/${TAG}_rehearsal_5ranks_*.json $OUT/
 echo "== rocprofv3" ; date
 WORKLOAD="bu3dfe-rgbd-96:96v/gpu" timeout -k 10 1200 bash tools/profile_gpu.sh $TAG > $OUT/profile_log.txt 2>&1 || exit 1
 P=$ROOT/gpurun_out/prof_$TAG
@@ -45,6 +46,12 @@ cp $P/kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 cp $P/pmc_summary.txt $OUT/${TAG}_pmc_summary.txt
 cp $P/traffic.json $OUT/${TAG}_traffic.json
 cp $P/bench_trace.json $OUT/${TAG}_bench_under_rocprof.json
+echo "== rocprofv3, the opt-in f16x2 precision" ; date
+WORKLOAD="bu3dfe-rgbd-96:96v/gpu" timeout -k 10 900 bash tools/profile_gpu.sh ${TAG}_fast16 --precision fast16 > $OUT/profile_log_fast16.txt 2>&1 || exit 1
+P=$ROOT/gpurun_out/prof_${TAG}_fast16
+cp $P/kernel_stats.csv $OUT/${TAG}_fast16_kernel_stats.csv
+cp $P/pmc_summary.txt $OUT/${TAG}_fast16_pmc_summary.txt
+cp $P/bench_trace.json $OUT/${TAG}_fast16_bench_under_rocprof.json
 echo "== rocprofv3, the 12-view shard (paired launches, split-K tiles)" ; date
 WORKLOAD="dtu3d-geomdepth-96:12v/gpu" timeout -k 10 900 bash tools/profile_gpu.sh ${TAG}_12views --config dtu3d-geomdepth-96 --views-total 12 > $OUT/profile_log_12views.txt 2>&1 || exit 1
 P=$ROOT/gpurun_out/prof_${TAG}_12views
