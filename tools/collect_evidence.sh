@@ -2,11 +2,16 @@
 # Everything profiles/README.md cites for one round, in one pass on the GPU box: usage tools/collect_evidence.sh r04
 # (results under gpurun_out/evidence_<tag>/ with the names they get in profiles/)
 set -u
+# PART=a: benches, parity reports, rehearsals; PART=b: the rocprofv3 passes and kernel traces; default both (a gpurun call ends
+# after 20 minutes: the two halves fit one call each)
 TAG=${1:-r04}
+PART=${PART:-ab}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/evidence_$TAG
-rm -rf $OUT; mkdir -p $OUT
+[[ $PART == *a* ]] && rm -rf $OUT
+mkdir -p $OUT
 cd $ROOT
+if [[ $PART == *a* ]]; then
 echo "== default bench" ; date
 timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.stderr.txt || exit 1
 export MVLM_BENCH_NO_INGEST=1
@@ -39,6 +44,9 @@ python3 tools/per_level_table.py $OUT/per_layer_96.err > $OUT/${TAG}_per_level_9
 echo "== bench.py --gpus 5 as a plain process (five gloo ranks sharing this GPU: the box's process guard admits six processes), configs[2] / [3] / [4] at the 8-GPU shard sizes" ; date
 timeout -k 10 900 bash tools/r5_rehearsal.sh $TAG > $OUT/rehearsal_log.txt 2>&1 || exit 1
 cp $ROOT/gpurun_out/rehearsal_$TAG/${TAG}_rehearsal_5ranks_*.json $OUT/
+fi
+if [[ $PART == *b* ]]; then
+export MVLM_BENCH_NO_INGEST=1
 echo "== rocprofv3" ; date
 WORKLOAD="bu3dfe-rgbd-96:96v/gpu" timeout -k 10 1200 bash tools/profile_gpu.sh $TAG > $OUT/profile_log.txt 2>&1 || exit 1
 P=$ROOT/gpurun_out/prof_$TAG
@@ -63,4 +71,5 @@ timeout -k 10 300 bash tools/raster_trace.sh raster_$TAG > /dev/null 2>&1 || exi
 (cat $ROOT/gpurun_out/raster_$TAG/bench.txt; echo; cat $ROOT/gpurun_out/raster_$TAG/kernels.txt) > $OUT/${TAG}_raster_trace.txt
 timeout -k 10 300 bash tools/probes/profile_mediapipe_config.sh > /dev/null 2>&1 || exit 1
 cut -c1-260 $ROOT/gpurun_out/mp478/kernel_stats.csv | head -24 > $OUT/${TAG}_mediapipe_kernel_stats.csv
+fi
 date; ls -la $OUT
