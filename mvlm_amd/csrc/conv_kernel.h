@@ -68,7 +68,7 @@ struct Cfg {
     static constexpr int ACC_REGS = (COUT_T / 32) * (SPLITK ? PIX_T / 32 : TW * TRI * NIMG / 128) * 16 + (TAIL16 ? 4 * NT16 : 0) + (TAIL4 ? 4 : 0);
     // register budget per lane: 168 at three workgroups per CU, 256 at two
     // (four per CU = 128 registers makes the 64-accumulator tiles spill; measured slower)
-    static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256 && 3 * LDS_BYTES <= 160 * 1024) ? 3 : 2;  // (a tile whose LDS admits two keeps their 256 registers)
+    static constexpr int MIN_BLOCKS_PER_CU = (ACC_REGS <= 64 && TW * TRI * NIMG <= 256) ? 3 : 2;
     // fused 2x2 max-pool in the epilogue.  POOL32: the 32-pixel-row tiles - the rows of a pair are two pixel registers of a
     // lane, the columns two neighbouring lanes.  POOL_SMALL (round 5): tiles narrower than 32 pixels (and the split-K tiles) -
     // a 32-pixel MFMA column then holds 32 / TW consecutive rows of ONE image, so the row partner of lane l is lane l ^ TW and

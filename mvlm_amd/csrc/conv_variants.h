@@ -63,11 +63,7 @@
     X(30, "conv3x3_sk16_t8x8", Cfg<32, 8, 8, 1, 3, 16, true>) \
     X(31, "conv3x3_sk8_t8x8", Cfg<32, 8, 8, 1, 3, 8, true>) \
     X(32, "conv3x3_sk16_t4x16", Cfg<32, 16, 4, 1, 3, 16, true>)
-// round 5 experiment: the 64-channel 8x32 tile with 8-channel chunks - the work per staged element and per barrier of the dominant
-// 128-channel tile (144 MFMAs per chunk and wave instead of 72), two workgroups per CU (61 KB of LDS) instead of three
-#define MVLM_CONV_VARIANTS_G16(X) \
-    X(33, "conv3x3_c64k8_t8x32", Cfg<64, 32, 8, 1, 3, 8>)
 #define MVLM_CONV_VARIANTS(X) \
-    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X) MVLM_CONV_VARIANTS_G13(X) MVLM_CONV_VARIANTS_G14(X) MVLM_CONV_VARIANTS_G15(X) MVLM_CONV_VARIANTS_G16(X)
-#define MVLM_CONV_N_GROUPS 17
+    MVLM_CONV_VARIANTS_G0(X) MVLM_CONV_VARIANTS_G1(X) MVLM_CONV_VARIANTS_G2(X) MVLM_CONV_VARIANTS_G3(X) MVLM_CONV_VARIANTS_G4(X) MVLM_CONV_VARIANTS_G5(X) MVLM_CONV_VARIANTS_G6(X) MVLM_CONV_VARIANTS_G7(X) MVLM_CONV_VARIANTS_G8(X) MVLM_CONV_VARIANTS_G9(X) MVLM_CONV_VARIANTS_G10(X) MVLM_CONV_VARIANTS_G11(X) MVLM_CONV_VARIANTS_G12(X) MVLM_CONV_VARIANTS_G13(X) MVLM_CONV_VARIANTS_G14(X) MVLM_CONV_VARIANTS_G15(X)
+#define MVLM_CONV_N_GROUPS 16
 #endif

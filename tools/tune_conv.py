@@ -20,7 +20,7 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))
 
-N_VARIANTS = 34
+N_VARIANTS = 33
 # tiles that fold several images into one MFMA column are only used at the level they were written for
 NATIVE_WIDTH = {"conv3x3_c32_t8x8x2": 8, "conv3x3_c32_t4x4x8": 4, "conv3x3_sk_t4x4x2": 4, "conv3x3_sk16_t4x4x2": 4, "conv3x3_sk8_t4x4x2": 4}
 HEADER = REPO / "mvlm_amd" / "csrc" / "conv_tuned.h"

@@ -28,7 +28,7 @@ import numpy as np
 REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))
 HEADER = REPO / "mvlm_amd" / "csrc" / "conv_tuned_net.h"
-N_VARIANTS = 34
+N_VARIANTS = 33
 CAP = 1024
 
 
