@@ -1,5 +1,6 @@
 // Context, mesh upload and the single-convolution test hook of the C ABI
 // (include/mvlm_hip.h).
+#include <atomic>
 #include <cstring>
 
 #include "common.h"
@@ -168,6 +169,8 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
         if (bytes[i]) std::memcpy(stage + off[i], src[i], bytes[i]);
 
     auto* m = new mvlm_mesh();
+    static std::atomic<unsigned long long> next_uid{1};
+    m->uid = next_uid.fetch_add(1);
     m->n_verts = n_verts;
     m->n_tris = n_tris;
     void** dst[4] = {(void**)&m->verts, (void**)&m->uvs, (void**)&m->tris, (void**)&m->tex};

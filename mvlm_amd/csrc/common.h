@@ -191,6 +191,7 @@ struct mvlm_mesh {
     int32_t* tris = nullptr;  // [T,3]
     uint8_t* tex = nullptr;   // [H,W,3] or null
     int n_verts = 0, n_tris = 0, tex_h = 0, tex_w = 0;
+    unsigned long long uid = 0;  // unique per upload (an address can be recycled): key of per-mesh derived data a context keeps
     size_t cap[4] = {0, 0, 0, 0};  // allocation sizes of verts / uvs / tris / tex (for the ctx's mesh pool)
     // recorded on the context's upload stream behind the four host-to-device copies; every consumer's stream waits for it
     hipEvent_t ready = nullptr;
@@ -223,6 +224,10 @@ struct mvlm_ctx {
     // stream (which cannot be destroyed) records nothing; from its first change of stream on, every entry point leaves
     // switch_event behind the work it enqueued (MvlmOrderGuard), so a later change never touches the previous stream's
     // handle - its owner may have destroyed it by then.
+    // surface snap: which upload the scratch's de-indexed triangle copy and vertex -> triangle table were made for
+    unsigned long long snap_mesh_uid = 0;
+    const void* snap_soup = nullptr;
+    const void* snap_vert_tri = nullptr;
     hipEvent_t switch_event = nullptr;
     bool track_order = false;      // the context has been moved between streams: record switch_event at every exit
     bool order_recorded = false;   // switch_event stands behind everything enqueued so far

@@ -442,9 +442,16 @@ extern "C" int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, con
     auto* cand_v = static_cast<int*>(ctx->get_scratch("project.cand_v", size_t(n_points) * BOUND_SPLIT * sizeof(int)));
     MVLM_REQUIRE(ctx, part_d && part_t && ub && soup && vert_tri && cand_d && cand_v, "project_to_surface: scratch allocation failed");
     MVLM_REQUIRE(ctx, n_points <= 65535, "project_to_surface: at most 65535 points per call");
-    MVLM_CHECK_HIP(ctx, hipMemsetAsync(vert_tri, 0x7f, size_t(mesh->n_verts) * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(project_soup_kernel, dim3((mesh->n_tris + 255) / 256), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris,
-                       mesh->n_tris, soup, vert_tri);
+    // the de-indexed triangles and the vertex -> triangle table depend on the mesh only: kept in the context's scratch from call
+    // to call of the same upload (a pipeline snaps every scan once, bench and folders of one mesh many times)
+    if (ctx->snap_mesh_uid != mesh->uid || ctx->snap_soup != soup || ctx->snap_vert_tri != vert_tri) {
+        MVLM_CHECK_HIP(ctx, hipMemsetAsync(vert_tri, 0x7f, size_t(mesh->n_verts) * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(project_soup_kernel, dim3((mesh->n_tris + 255) / 256), dim3(256), 0, ctx->stream, mesh->verts, mesh->tris,
+                           mesh->n_tris, soup, vert_tri);
+        ctx->snap_mesh_uid = mesh->uid;
+        ctx->snap_soup = soup;
+        ctx->snap_vert_tri = vert_tri;
+    }
     hipLaunchKernelGGL(project_bound_kernel, dim3(n_points, BOUND_SPLIT), dim3(256), 0, ctx->stream, mesh->verts, mesh->n_verts,
                        vert_tri, pts_dev, cand_d, cand_v);
     hipLaunchKernelGGL(project_bound_pick_kernel, dim3((n_points + 63) / 64), dim3(64), 0, ctx->stream, mesh->verts, mesh->tris,
