@@ -112,6 +112,19 @@ __device__ void pinv3_apply(const double s_in[6], const double c[3], double p[3]
             for (int qi = pi + 1; qi < 3; ++qi) {
                 const double apq = a[pi][qi];
                 if (apq == 0.0) continue;
+                // After a few sweeps an off-diagonal element that no longer registers beside BOTH of its diagonal elements
+                // (|a_pp| + 100 |a_pq| == |a_pp| in double arithmetic) is set to zero instead of rotated (the classical cyclic
+                // Jacobi termination): its rotation would move the eigenvalues by less than an ulp, and without this the
+                // two-sided update never leaves an exact 0.0 behind, so every solve ran all 30 sweeps - 45 of the kernel's
+                // 68 us, on one wavefront per landmark (round 5).
+                if (sweep > 2) {
+                    const double g = 100.0 * fabs(apq);
+                    if (fabs(a[pi][pi]) + g == fabs(a[pi][pi]) && fabs(a[qi][qi]) + g == fabs(a[qi][qi])) {
+                        a[pi][qi] = 0.0;
+                        a[qi][pi] = 0.0;
+                        continue;
+                    }
+                }
                 const double theta = (a[qi][qi] - a[pi][pi]) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
