@@ -251,7 +251,7 @@ def test_four_ranks_at_the_twelve_view_shard_size_equal_the_single_process(tmp_p
 def test_eight_way_shard_of_configs3_equals_the_single_process():
     """The 8-GPU form of configs[3] - 96 views, rank r renders and predicts views [12 r, 12 r + 12) - evaluated shard by
     shard in this one process (eight ranks on one card exceed the box's process guard; the collectives themselves run with
-    eight gloo ranks in tests/test_distributed_cpu.py and with five GPU ranks above): the gathered maxima and the fused
+    eight gloo ranks in tests/test_distributed_cpu.py and with four GPU ranks above): the gathered maxima and the fused
     landmarks equal, bit for bit, the single process that runs the 96 views through the network 12 at a time, and stay
     within the oracle bound of the single process that runs them 96 at a time."""
     from mvlm_amd import parallel
