@@ -11,7 +11,6 @@ the reference's landmarks.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -52,8 +51,7 @@ class HipEstimator3D:
         caller promises not to change torch's current stream in between."""
         if on:
             self._pinned_stream = None
-            if os.environ.get("MVLM_PIN_STREAM", "1") != "0":  # ("0": A/B measurements)
-                _, self._pinned_stream = self._torch()
+            _, self._pinned_stream = self._torch()
         else:
             self._pinned_stream = None
 
