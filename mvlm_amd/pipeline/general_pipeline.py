@@ -288,17 +288,6 @@ class Pipeline(abc.ABC):
             draws_fn.device_result = True  # plan_draws may ask for the collective's device tensor (RCCL)
 
         nl_all = p2.get_lm_count()
-        e3.pin_stream(True)  # one `current stream` lookup for the estimator's nine calls of this mesh (released below)
-        try:
-            return self._predict_mesh_device_pinned(mesh, transform_stack, rot, n_total, sharded, rank, world, lo, hi, draws_fn, nl_all)
-        finally:
-            e3.pin_stream(False)
-
-    def _predict_mesh_device_pinned(self, mesh, transform_stack, rot, n_total, sharded, rank, world, lo, hi, draws_fn, nl_all):
-        import torch
-
-        r3, p2, e3 = self.renderer_3d, self.predictor_2d, self.estimator_3d
-        tm = self._timer
         # sharded: the draws come out of a collective, which must not queue up behind this step's network
         plan = e3.plan_draws(nl_all, n_total, draws_fn) if sharded else None
         rot_dev = e3.upload_rotations(rot)

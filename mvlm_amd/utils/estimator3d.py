@@ -33,27 +33,14 @@ class HipEstimator3D:
         self.ctx = _lib.get_context(device)
         self._upload_stream = None
         self._draw_bufs: dict = {}
-        self._pinned_stream = None  # the device while a pipeline call has pinned the stream (see pin_stream)
 
     # ---- helpers ----------------------------------------------------------------------
     def _torch(self):
         import torch
 
-        if self._pinned_stream is not None:  # inside Pipeline.predict_mesh_device: stream looked up once per call
-            return torch, self._pinned_stream
         dev = torch.device("cuda", self.ctx.device)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         return torch, dev
-
-    def pin_stream(self, on: bool):
-        """Between pin_stream(True) and pin_stream(False) the estimator's methods skip their own `current stream` lookup
-        (5 us each, nine per mesh: a third of a millisecond-scale step like the 478-landmark fusion without a network); the
-        caller promises not to change torch's current stream in between."""
-        if on:
-            self._pinned_stream = None
-            _, self._pinned_stream = self._torch()
-        else:
-            self._pinned_stream = None
 
     def upload_rotations(self, rot: np.ndarray):
         """[N,9] float64 view rotations -> device tensor.  A host-to-device copy from ordinary memory waits for the
@@ -279,8 +266,10 @@ class HipEstimator3D:
     @staticmethod
     def mean_error(err_per_landmark: np.ndarray) -> float:
         """sum_error / n_landmarks with the reference's left-to-right accumulation (:180-183)."""
-        # (np.cumsum adds strictly left to right - the loop `s = 0; for e: s = s + e` of the reference, not numpy's pairwise sum)
-        return float(np.cumsum(np.asarray(err_per_landmark, dtype=np.float64))[-1]) / len(err_per_landmark)
+        s = 0
+        for e in err_per_landmark:
+            s = s + float(e)
+        return s / len(err_per_landmark)
 
     # ---- the reference's numpy-in / numpy-out slot methods ----------------------------
     def estimate_landmark_lines(self, image_stack: np.ndarray, landmarks_stack: np.ndarray, transform_stack: np.ndarray):
