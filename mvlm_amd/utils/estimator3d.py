@@ -266,10 +266,8 @@ class HipEstimator3D:
     @staticmethod
     def mean_error(err_per_landmark: np.ndarray) -> float:
         """sum_error / n_landmarks with the reference's left-to-right accumulation (:180-183)."""
-        s = 0
-        for e in err_per_landmark:
-            s = s + float(e)
-        return s / len(err_per_landmark)
+        # (np.cumsum adds strictly left to right - the loop `s = 0; for e: s = s + e` of the reference, not numpy's pairwise sum)
+        return float(np.cumsum(np.asarray(err_per_landmark, dtype=np.float64))[-1]) / len(err_per_landmark)
 
     # ---- the reference's numpy-in / numpy-out slot methods ----------------------------
     def estimate_landmark_lines(self, image_stack: np.ndarray, landmarks_stack: np.ndarray, transform_stack: np.ndarray):
