@@ -327,7 +327,9 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            if share_gpu:
+            # MVLM_BENCH_BACKEND=gloo: one rank per GPU as always, the two small collectives of a step staged through the host
+            # (a way around an RCCL that will not initialise on some node; the default is RCCL = backend "nccl")
+            if share_gpu or os.environ.get("MVLM_BENCH_BACKEND") == "gloo":
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -558,7 +560,7 @@ def main():
                                             "accumulate, per-layer power-of-two weight scale); everything else exact fp32")
     per_rank_ms = None
     if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
         every = [torch.zeros_like(t) for _ in range(world)]
         torch.distributed.all_gather(every, t)
         per_rank_ms = [1e3 * float(v.item()) / args.steps for v in every]
