@@ -566,3 +566,41 @@ def test_soak_two_pipelines_alternating_stay_deterministic():
         assert np.array_equal(got_b[0], want_b[0]) and got_b[1] == want_b[1], f"call {i} of the 8-view pipeline changed"
     sa, sb = pa.predictor_2d.execution_stats(), pb.predictor_2d.execution_stats()
     assert sa["graph_replays"] >= 148 and sb["graph_replays"] >= 148 and sa["graph_failures"] == 0 and sb["graph_failures"] == 0
+
+
+# --------------------------------------------------------------------------------------
+# a network whose 138 convolutions all carry dense weights AND whose heatmaps are peaked (RANSAC inlier branch)
+@pytest.mark.parametrize("precision,n_views", [("exact", 16), ("exact", 48), ("fast16", 16), ("fast", 16)])
+def test_dense_planted_network_end_to_end(precision, n_views):
+    """tests/planted.py with dense_eps = 0.003: every convolution multiplies a full random weight tensor (their sum moves a
+    peak's height by up to 20 %), activations stay of order one like a trained network's, the heatmaps peak at the planted
+    surface points.  Render -> 138 convolutions -> fused argmax -> rays -> quantile filter -> one-shot RANSAC with its INLIER
+    refit -> snap against the oracle: >= 99 % identical argmax pixels, landmarks with identical maxima within 1e-3 model units,
+    the planted points found; the opt-in precisions run without leaving fp16's range."""
+    from mvlm_amd import arch, config
+    from mvlm_amd.pipeline import pipeline_from_config
+    from oracle import pipeline as opipe
+    from test_planted_cpu import planted_scene
+
+    mesh, pts, sd, poses = planted_scene(n_views=n_views, dense_eps=0.003)
+    pipe = pipeline_from_config(config.default_config("DTU3D", "RGB", n_views=n_views), weights=sd, verbose=False, precision=precision)
+    np.random.seed(1)
+    got, gerr = pipe.predict_mesh_device(mesh, poses)
+    assert pipe.predictor_2d.precision == precision and pipe.predictor_2d.fast16_fallbacks == 0
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        want, werr, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses, sd, arch.CHANNEL_SELECT["RGB"])
+    assert werr < 10.0 and gerr < 10.0               # inlier branch for every landmark (a fallback adds 1e8 / NL)
+    images = pipe.renderer_3d.render_device(mesh, poses)
+    assert np.array_equal(images.cpu().numpy(), inter["images"])
+    gmax = pipe.predictor_2d.predict_device(images).cpu().numpy()
+    same_px = np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)
+    assert same_px.mean() >= 0.99, same_px.mean()
+    assert np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[same_px].max() < 2e-5
+    same = same_px.all(axis=1)
+    assert same.mean() > 0.8
+    assert np.abs(got[same] - want[same]).max() < 1e-3
+    if same.all():
+        assert abs(gerr - werr) < 1e-6 * max(1.0, werr)
+    d = np.linalg.norm(got - pts, axis=1)
+    assert d.max() < 8.0 and np.median(d) < 4.0
