@@ -596,7 +596,8 @@ def test_dense_planted_network_end_to_end(precision, n_views):
     gmax = pipe.predictor_2d.predict_device(images).cpu().numpy()
     same_px = np.all(gmax[:, :, :2] == inter["maxima"][:, :, :2], axis=2)
     assert same_px.mean() >= 0.99, same_px.mean()
-    assert np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[same_px].max() < 2e-5
+    # (peak heights of ~0.25 are differences of hinge features of order one: 2e-4 of THAT scale, the whole-network tolerance)
+    assert np.abs(gmax[:, :, 2] - inter["maxima"][:, :, 2])[same_px].max() < 2e-4
     same = same_px.all(axis=1)
     assert same.mean() > 0.8
     assert np.abs(got[same] - want[same]).max() < 1e-3
