@@ -570,8 +570,12 @@ def test_soak_two_pipelines_alternating_stay_deterministic():
 
 # --------------------------------------------------------------------------------------
 # a network whose 138 convolutions all carry dense weights AND whose heatmaps are peaked (RANSAC inlier branch)
-@pytest.mark.parametrize("precision,n_views", [("exact", 16), ("exact", 48), ("fast16", 16), ("fast", 16)])
-def test_dense_planted_network_end_to_end(precision, n_views):
+@pytest.mark.parametrize("dataset,mode,nl,precision,n_views", [
+    ("DTU3D", "RGB", 73, "exact", 16), ("DTU3D", "RGB", 73, "exact", 48), ("DTU3D", "RGB", 73, "fast16", 16), ("DTU3D", "RGB", 73, "fast", 16),
+    ("BU_3DFE", "RGB+depth", 84, "exact", 96),    # the bench configuration's network and view count
+    ("BU_3DFE", "RGB+depth", 84, "fast16", 96),
+])
+def test_dense_planted_network_end_to_end(dataset, mode, nl, precision, n_views):
     """tests/planted.py with dense_eps = 0.003: every convolution multiplies a full random weight tensor (their sum moves a
     peak's height by up to 20 %), activations stay of order one like a trained network's, the heatmaps peak at the planted
     surface points.  Render -> 138 convolutions -> fused argmax -> rays -> quantile filter -> one-shot RANSAC with its INLIER
@@ -582,14 +586,14 @@ def test_dense_planted_network_end_to_end(precision, n_views):
     from oracle import pipeline as opipe
     from test_planted_cpu import planted_scene
 
-    mesh, pts, sd, poses = planted_scene(n_views=n_views, dense_eps=0.003)
-    pipe = pipeline_from_config(config.default_config("DTU3D", "RGB", n_views=n_views), weights=sd, verbose=False, precision=precision)
+    mesh, pts, sd, poses = planted_scene(nl=nl, mode=mode, n_views=n_views, dense_eps=0.003)
+    pipe = pipeline_from_config(config.default_config(dataset, mode, n_views=n_views), weights=sd, verbose=False, precision=precision)
     np.random.seed(1)
     got, gerr = pipe.predict_mesh_device(mesh, poses)
     assert pipe.predictor_2d.precision == precision and pipe.predictor_2d.fast16_fallbacks == 0
     np.random.seed(1)
     with contextlib.redirect_stdout(io.StringIO()):
-        want, werr, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses, sd, arch.CHANNEL_SELECT["RGB"])
+        want, werr, inter = opipe.predict_mesh(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses, sd, arch.CHANNEL_SELECT[mode])
     assert werr < 10.0 and gerr < 10.0               # inlier branch for every landmark (a fallback adds 1e8 / NL)
     images = pipe.renderer_3d.render_device(mesh, poses)
     assert np.array_equal(images.cpu().numpy(), inter["images"])
