@@ -184,6 +184,55 @@ def committed_traffic(workload_key: str, kernel: str):
     return None, None
 
 
+def live_traffic(variant_name: str, argv: list[str]):
+    """HBM bytes per launch of the dominant convolution kernel MEASURED for this invocation: two separate rocprofv3 `--pmc`
+    passes (FETCH_SIZE, WRITE_SIZE; kernel trace only, as MI355X_MICROARCH.md prescribes) of a short child run of this same
+    script on the same workload, 2 x FETCH_SIZE + WRITE_SIZE (KB) per dispatch of that kernel (gfx950 counts half the bytes
+    of wide reads).  The children start as ordinary subprocesses (`rocprofv3 ... -- python3 bench.py ...`) after the timed
+    region; any failure (no rocprofv3, counters unavailable) returns (None, reason) and the committed profile is quoted."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists():
+        return None, "rocprofv3 not found"
+    cfg = None  # template arguments of the variant's Cfg<...>, from the variant table itself
+    for m in re.finditer(r'X\((\d+), "([^"]+)", Cfg<([^>]*)>\)', (REPO / "mvlm_amd" / "csrc" / "conv_variants.h").read_text()):
+        if m[2] == variant_name:
+            cfg = m[3]
+    if cfg is None:
+        return None, f"no Cfg<> for {variant_name}"
+    total = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="mvlm_pmc_", dir="/tmp")
+        env = dict(os.environ, MVLM_BENCH_NO_INGEST="1", MVLM_BENCH_CHILD="1", TMPDIR="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+               str(Path(__file__).resolve())] + argv + ["--steps", "1", "--warmup", "0", "--cpu-views", "0", "--no-fast-mode"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        except Exception as e:  # noqa: BLE001
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"rocprofv3 {counter} pass failed: {e}"
+        kb, n = 0.0, 0
+        for f in Path(out).rglob("*counter_collection.csv"):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    k = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") == counter and f"Cfg<{cfg}>" in k.replace(", false>", ">") and "conv_mfma_kernel" in k \
+                            and re.search(r">, false(, false)?>", k):
+                        kb += float(row.get("Counter_Value", 0) or 0)
+                        n += 1
+        shutil.rmtree(out, ignore_errors=True)
+        if r.returncode != 0 or n == 0:
+            return None, f"rocprofv3 {counter} pass gave no counters (rc {r.returncode})"
+        total[counter] = (kb, n)
+    (f_kb, nf), (w_kb, nw) = total["FETCH_SIZE"], total["WRITE_SIZE"]
+    return round(2 * f_kb * 1024 / nf + w_kb * 1024 / nw), f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this invocation ({nf} dispatches each)"
+
+
 def visible_gpus() -> int:
     """GPUs a child rank could open, counted from sysfs: no HIP / HSA call, no torch import - this process is the parent of
     the ranks and must not touch the GPU.  A GPU is a KFD topology node with SIMDs whose render node this process may
@@ -285,6 +334,8 @@ def main():
                          "record the events over the same number of steps right after the timed region")
     ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra pass that measures the opt-in fast precision")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="quote roofline.traffic from the committed PMC profile instead of measuring it with two rocprofv3 --pmc child passes")
     ap.add_argument("--precision", default="exact", choices=["exact", "fast", "fast16"], help=argparse.SUPPRESS)  # experiments: time the fast path as the main loop
     ap.add_argument("--selection", default="simple", choices=["simple", "moment"],
                     help="heatmap maxima (paulsenpredictor.py:112-158): the argmax pixel (default) or the 31x31 centroid around it - both fused")
@@ -592,7 +643,20 @@ def main():
             total_f = sum(p[0] for p in prof.values())
             total_ms = sum(p[1] for p in prof.values())
             name = lib.mvlm_conv_variant_name(dom).decode()
-            traffic, src = committed_traffic(workload_key, name)
+            traffic, src = None, None
+            if (world == 1 and not args.no_live_traffic and not os.environ.get("MVLM_BENCH_CHILD") and args.precision == "exact"
+                    and os.environ.get("MVLM_BENCH_LIVE_TRAFFIC", "1") != "0"):
+                child_args = ["--config", args.config, "--device-batch", str(args.device_batch), "--selection", args.selection]
+                if args.views_total:
+                    child_args += ["--views-total", str(args.views_total)]
+                t0 = time.time()
+                traffic, src = live_traffic(name, child_args)
+                log(f"roofline.traffic: {traffic} bytes per launch of {name} ({src}; {time.time() - t0:.0f} s)")
+            if traffic is None:
+                why = src
+                traffic, src = committed_traffic(workload_key, name)
+                if src and why:
+                    src = f"{src} (committed profile; live measurement unavailable: {why})"
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                     "kernel": name, "kernel_avg_ms": round(t_ms / cnt, 4),

@@ -13,8 +13,8 @@ mkdir -p $OUT
 cd $ROOT
 if [[ $PART == *a* ]]; then
 echo "== default bench" ; date
-timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.stderr.txt || exit 1
-export MVLM_BENCH_NO_INGEST=1
+timeout -k 10 900 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.stderr.txt || exit 1
+export MVLM_BENCH_NO_INGEST=1 MVLM_BENCH_LIVE_TRAFFIC=0
 echo "== other configs" ; date
 timeout -k 10 300 python3 bench.py --config bu3dfe-depth-8 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_b8views.json 2> $OUT/${TAG}_bench_b8views.stderr.txt || exit 1
 timeout -k 10 300 python3 bench.py --config dtu3d-rgb-64 --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_dtu3d_rgb_64views.json 2> /dev/null || exit 1
@@ -46,7 +46,7 @@ timeout -k 10 900 bash tools/r5_rehearsal.sh $TAG > $OUT/rehearsal_log.txt 2>&1 
 cp $ROOT/gpurun_out/rehearsal_$TAG/${TAG}_rehearsal_5ranks_*.json $OUT/
 fi
 if [[ $PART == *b* ]]; then
-export MVLM_BENCH_NO_INGEST=1
+export MVLM_BENCH_NO_INGEST=1 MVLM_BENCH_LIVE_TRAFFIC=0
 echo "== rocprofv3" ; date
 WORKLOAD="bu3dfe-rgbd-96:96v/gpu" timeout -k 10 1200 bash tools/profile_gpu.sh $TAG > $OUT/profile_log.txt 2>&1 || exit 1
 P=$ROOT/gpurun_out/prof_$TAG

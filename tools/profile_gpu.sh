@@ -8,7 +8,7 @@ TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp MVLM_BENCH_NO_INGEST=1
+cd /tmp && export TMPDIR=/tmp MVLM_BENCH_NO_INGEST=1 MVLM_BENCH_LIVE_TRAFFIC=0
 ARGS="--steps 3 --warmup 2 --cpu-views 0 --no-fast-mode $*"
 echo "== kernel trace" | tee -a $OUT/log.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err

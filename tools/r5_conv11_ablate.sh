@@ -2,6 +2,7 @@
 # What would a conv11 kernel gain that stages its input tile once for all four parities?  Timing-only builds of the 2x2 parity
 # tile (conv2x2_c84_t8x32, variant 29; wrong results) with parts switched off, conv11's launch time read from a network pass.
 set -u
+export MVLM_BENCH_LIVE_TRAFFIC=0
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/mvlm_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result -Wno-unused-value"

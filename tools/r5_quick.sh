@@ -1,6 +1,7 @@
 #!/bin/bash
 # quick round-5 measurement set on the GPU box: small batches (12 / 8 views) with per-layer tables, fast16 per layer
 set -u
+export MVLM_BENCH_LIVE_TRAFFIC=0
 TAG=${1:-q}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/quick_$TAG

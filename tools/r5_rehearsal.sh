@@ -7,6 +7,7 @@
 # rank (60 views in total), configs[4] 16 per rank (80 in total); configs[2] runs its 96 views on 5 ranks (19-20 per rank).
 # usage: tools/r5_rehearsal.sh <tag>   -> gpurun_out/rehearsal_<tag>/<tag>_rehearsal_5ranks_*.json (+ wall seconds of each whole command)
 set -u
+export MVLM_BENCH_LIVE_TRAFFIC=0
 TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/rehearsal_$TAG
