@@ -18,6 +18,10 @@ With N GPUs the SAME 96 views are sharded 96/N per rank (strong scaling - BASELI
 before fusion; `--scaling weak` keeps 96 views per GPU instead.  Other BASELINE configurations:
 `--config dtu3d-rgb-64 | bu3dfe-depth-8 | dtu3d-geomdepth-96 | mediapipe-478x128`.
 
+roofline.traffic (HBM bytes per launch of the dominant kernel) is measured by the N = 1 invocation itself with two short
+rocprofv3 --pmc child passes after the timed region (live_traffic); --no-live-traffic / MVLM_BENCH_LIVE_TRAFFIC=0 quote the
+committed profiles/rNN_traffic.json instead.
+
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 from __future__ import annotations
