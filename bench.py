@@ -188,8 +188,9 @@ def committed_traffic(workload_key: str, kernel: str):
     return None, None
 
 
-def live_traffic(variant_name: str, argv: list[str]):
-    """HBM bytes per launch of the dominant convolution kernel MEASURED for this invocation: two separate rocprofv3 `--pmc`
+def live_traffic(variant_name: str | None, argv: list[str]):
+    """-> (bytes per launch of the dominant convolution kernel | None, source text, bytes per render call of the rasteriser | None).
+    HBM bytes per launch of the dominant convolution kernel (and of the rasteriser's five kernels) MEASURED for this invocation: two separate rocprofv3 `--pmc`
     passes (FETCH_SIZE, WRITE_SIZE; kernel trace only, as MI355X_MICROARCH.md prescribes) of a short child run of this same
     script on the same workload, 2 x FETCH_SIZE + WRITE_SIZE (KB) per dispatch of that kernel (gfx950 counts half the bytes
     of wide reads).  The children start as ordinary subprocesses (`rocprofv3 ... -- python3 bench.py ...`) after the timed
@@ -202,14 +203,15 @@ def live_traffic(variant_name: str, argv: list[str]):
 
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists():
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     cfg = None  # template arguments of the variant's Cfg<...>, from the variant table itself
     for m in re.finditer(r'X\((\d+), "([^"]+)", Cfg<([^>]*)>\)', (REPO / "mvlm_amd" / "csrc" / "conv_variants.h").read_text()):
         if m[2] == variant_name:
             cfg = m[3]
-    if cfg is None:
-        return None, f"no Cfg<> for {variant_name}"
-    total = {}
+    if variant_name and cfg is None:
+        return None, f"no Cfg<> for {variant_name}", None
+    RASTER = ("transform_kernel", "classify_kernel", "scan_kernel", "bin_fill_kernel", "tile_kernel")
+    total, raster = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="mvlm_pmc_", dir="/tmp")
         env = dict(os.environ, MVLM_BENCH_NO_INGEST="1", MVLM_BENCH_CHILD="1", TMPDIR="/tmp")
@@ -219,22 +221,33 @@ def live_traffic(variant_name: str, argv: list[str]):
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
         except Exception as e:  # noqa: BLE001
             shutil.rmtree(out, ignore_errors=True)
-            return None, f"rocprofv3 {counter} pass failed: {e}"
-        kb, n = 0.0, 0
+            return None, f"rocprofv3 {counter} pass failed: {e}", None
+        kb, n, rkb, rn = 0.0, 0, 0.0, 0
         for f in Path(out).rglob("*counter_collection.csv"):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
+                    if row.get("Counter_Name") != counter:
+                        continue
                     k = row.get("Kernel_Name", "")
-                    if row.get("Counter_Name") == counter and f"Cfg<{cfg}>" in k.replace(", false>", ">") and "conv_mfma_kernel" in k \
-                            and re.search(r">, false(, false)?>", k):
-                        kb += float(row.get("Counter_Value", 0) or 0)
+                    v = float(row.get("Counter_Value", 0) or 0)
+                    if variant_name and f"Cfg<{cfg}>" in k.replace(", false>", ">") and "conv_mfma_kernel" in k and re.search(r">, false(, false)?>", k):
+                        kb += v
                         n += 1
+                    elif any(("::" + name + "(") in k or ("::" + name + "<") in k for name in RASTER):
+                        rkb += v            # the five kernels of one mvlm_render together, per render call
+                        rn += 1 if "::tile_kernel" in k else 0
         shutil.rmtree(out, ignore_errors=True)
-        if r.returncode != 0 or n == 0:
-            return None, f"rocprofv3 {counter} pass gave no counters (rc {r.returncode})"
+        if r.returncode != 0 or (variant_name and n == 0) or rn == 0:
+            return None, f"rocprofv3 {counter} pass gave no counters (rc {r.returncode})", None
         total[counter] = (kb, n)
+        raster[counter] = (rkb, rn)
+    (rf_kb, rnf), (rw_kb, rnw) = raster["FETCH_SIZE"], raster["WRITE_SIZE"]
+    raster_bytes = round(2 * rf_kb * 1024 / rnf + rw_kb * 1024 / rnw)
+    if not variant_name:
+        return None, f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this invocation ({rnf} renders each)", raster_bytes
     (f_kb, nf), (w_kb, nw) = total["FETCH_SIZE"], total["WRITE_SIZE"]
-    return round(2 * f_kb * 1024 / nf + w_kb * 1024 / nw), f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this invocation ({nf} dispatches each)"
+    return (round(2 * f_kb * 1024 / nf + w_kb * 1024 / nw),
+            f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this invocation ({nf} dispatches each)", raster_bytes)
 
 
 def visible_gpus() -> int:
@@ -629,13 +642,24 @@ def main():
         # rasteriser: HBM-bound.  Algorithmic bytes per view: mesh read V*20 B + T*12 B,
         # framebuffer write 256^2 * 16 B, one 3-byte texel per pixel at most
         ras_bytes_view = mesh.n_verts * 20 + mesh.n_tris * 12 + 256 * 256 * 16 + 256 * 256 * 3
+        # HBM traffic of this invocation's kernels by counters (two short rocprofv3 child passes), else the committed profile's
+        live = None
+        if (world == 1 and not args.no_live_traffic and not os.environ.get("MVLM_BENCH_CHILD") and args.precision == "exact"
+                and os.environ.get("MVLM_BENCH_LIVE_TRAFFIC", "1") != "0"):
+            child_args = ["--config", args.config, "--device-batch", str(args.device_batch), "--selection", args.selection]
+            if args.views_total:
+                child_args += ["--views-total", str(args.views_total)]
+            dom_name = cnn_ctx.lib.mvlm_conv_variant_name(max(prof, key=lambda k: prof[k][1])).decode() if prof else None
+            t0 = time.time()
+            live = live_traffic(dom_name, child_args)
+            log(f"live HBM traffic: {live} ({time.time() - t0:.0f} s)")
         roof_r = None
         if render_calls:
             avg_ms = render_ms / render_calls
             gbs = ras_bytes_view * n_local / (avg_ms * 1e-3) / 1e9
-            tr, src = committed_traffic(workload_key, "rasteriser")
+            tr, rsrc = (live[2], live[1]) if live and live[2] is not None else committed_traffic(workload_key, "rasteriser")
             roof_r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                      "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": tr, "kernel": "rasteriser (5 kernels of one mvlm_render)",
+                      "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": tr, "traffic_source": rsrc, "kernel": "rasteriser (5 kernels of one mvlm_render)",
                       "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes_per_view": ras_bytes_view,
                       "views_per_launch": n_local}
         roof = None
@@ -647,15 +671,7 @@ def main():
             total_f = sum(p[0] for p in prof.values())
             total_ms = sum(p[1] for p in prof.values())
             name = lib.mvlm_conv_variant_name(dom).decode()
-            traffic, src = None, None
-            if (world == 1 and not args.no_live_traffic and not os.environ.get("MVLM_BENCH_CHILD") and args.precision == "exact"
-                    and os.environ.get("MVLM_BENCH_LIVE_TRAFFIC", "1") != "0"):
-                child_args = ["--config", args.config, "--device-batch", str(args.device_batch), "--selection", args.selection]
-                if args.views_total:
-                    child_args += ["--views-total", str(args.views_total)]
-                t0 = time.time()
-                traffic, src = live_traffic(name, child_args)
-                log(f"roofline.traffic: {traffic} bytes per launch of {name} ({src}; {time.time() - t0:.0f} s)")
+            traffic, src = (live[0], live[1]) if live else (None, None)
             if traffic is None:
                 why = src
                 traffic, src = committed_traffic(workload_key, name)
