@@ -644,8 +644,10 @@ def main():
         ras_bytes_view = mesh.n_verts * 20 + mesh.n_tris * 12 + 256 * 256 * 16 + 256 * 256 * 3
         # HBM traffic of this invocation's kernels by counters (two short rocprofv3 child passes), else the committed profile's
         live = None
+        # (not when this process itself runs under a profiler: its preloaded tool library would be inherited by the children)
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         if (world == 1 and not args.no_live_traffic and not os.environ.get("MVLM_BENCH_CHILD") and args.precision == "exact"
-                and os.environ.get("MVLM_BENCH_LIVE_TRAFFIC", "1") != "0"):
+                and os.environ.get("MVLM_BENCH_LIVE_TRAFFIC", "1") != "0" and not profiled):
             child_args = ["--config", args.config, "--device-batch", str(args.device_batch), "--selection", args.selection]
             if args.views_total:
                 child_args += ["--views-total", str(args.views_total)]
