@@ -19,7 +19,7 @@ before fusion; `--scaling weak` keeps 96 views per GPU instead.  Other BASELINE 
 `--config dtu3d-rgb-64 | bu3dfe-depth-8 | dtu3d-geomdepth-96 | mediapipe-478x128`.
 
 roofline.traffic (HBM bytes per launch of the dominant kernel) is measured by the N = 1 invocation itself with two short
-rocprofv3 --pmc child passes after the timed region (live_traffic); --no-live-traffic / MVLM_BENCH_LIVE_TRAFFIC=0 quote the
+rocprofv3 --pmc child passes after the timed region (live_counters: HBM bytes and MFMA-busy of the dominant kernel); --no-live-traffic / MVLM_BENCH_LIVE_TRAFFIC=0 quote the
 committed profiles/rNN_traffic.json instead.
 
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
@@ -188,13 +188,16 @@ def committed_traffic(workload_key: str, kernel: str):
     return None, None
 
 
-def live_traffic(variant_name: str | None, argv: list[str]):
-    """-> (bytes per launch of the dominant convolution kernel | None, source text, bytes per render call of the rasteriser | None).
-    HBM bytes per launch of the dominant convolution kernel (and of the rasteriser's five kernels) MEASURED for this invocation: two separate rocprofv3 `--pmc`
-    passes (FETCH_SIZE, WRITE_SIZE; kernel trace only, as MI355X_MICROARCH.md prescribes) of a short child run of this same
-    script on the same workload, 2 x FETCH_SIZE + WRITE_SIZE (KB) per dispatch of that kernel (gfx950 counts half the bytes
-    of wide reads).  The children start as ordinary subprocesses (`rocprofv3 ... -- python3 bench.py ...`) after the timed
-    region; any failure (no rocprofv3, counters unavailable) returns (None, reason) and the committed profile is quoted."""
+def live_counters(variant_name: str | None, argv: list[str]):
+    """Counters of THIS invocation's kernels: three separate rocprofv3 `--pmc` child passes (FETCH_SIZE; WRITE_SIZE;
+    SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE - kernel trace only, no other trace domain, as MI355X_MICROARCH.md prescribes) of a
+    one-step run of this same script on the same workload, started as ordinary subprocesses after the timed region
+    (`rocprofv3 ... -- python3 bench.py ...`).  Returns a dict or (on any failure: no rocprofv3, no counters) {"error": reason}:
+      traffic          HBM bytes per launch of the dominant convolution kernel = 2 x FETCH_SIZE + WRITE_SIZE (KB) per dispatch
+                       (gfx950 counts half the bytes of wide reads)
+      raster_traffic   the same for the five kernels of one mvlm_render together, per render call
+      mfma_busy        SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the dominant kernel
+      source           how it was measured"""
     import csv
     import re
     import shutil
@@ -203,51 +206,52 @@ def live_traffic(variant_name: str | None, argv: list[str]):
 
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists():
-        return None, "rocprofv3 not found", None
+        return {"error": "rocprofv3 not found"}
     cfg = None  # template arguments of the variant's Cfg<...>, from the variant table itself
     for m in re.finditer(r'X\((\d+), "([^"]+)", Cfg<([^>]*)>\)', (REPO / "mvlm_amd" / "csrc" / "conv_variants.h").read_text()):
         if m[2] == variant_name:
             cfg = m[3]
     if variant_name and cfg is None:
-        return None, f"no Cfg<> for {variant_name}", None
+        return {"error": f"no Cfg<> for {variant_name}"}
     RASTER = ("transform_kernel", "classify_kernel", "scan_kernel", "bin_fill_kernel", "tile_kernel")
-    total, raster = {}, {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    dom, ras, n_dom, n_ras = {}, {}, 0, 0   # counter -> sum over the dispatches of the dominant kernel / the rasteriser's kernels
+    passes = (("FETCH_SIZE",), ("WRITE_SIZE",)) + ((("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"),) if variant_name else ())
+    for counters in passes:
         out = tempfile.mkdtemp(prefix="mvlm_pmc_", dir="/tmp")
         env = dict(os.environ, MVLM_BENCH_NO_INGEST="1", MVLM_BENCH_CHILD="1", TMPDIR="/tmp")
-        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                str(Path(__file__).resolve())] + argv + ["--steps", "1", "--warmup", "0", "--cpu-views", "0", "--no-fast-mode"]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
         except Exception as e:  # noqa: BLE001
             shutil.rmtree(out, ignore_errors=True)
-            return None, f"rocprofv3 {counter} pass failed: {e}", None
-        kb, n, rkb, rn = 0.0, 0, 0.0, 0
+            return {"error": f"rocprofv3 {'+'.join(counters)} pass failed: {e}"}
+        seen_dom = seen_ras = 0
         for f in Path(out).rglob("*counter_collection.csv"):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    if row.get("Counter_Name") != counter:
+                    c = row.get("Counter_Name")
+                    if c not in counters:
                         continue
                     k = row.get("Kernel_Name", "")
                     v = float(row.get("Counter_Value", 0) or 0)
                     if variant_name and f"Cfg<{cfg}>" in k.replace(", false>", ">") and "conv_mfma_kernel" in k and re.search(r">, false(, false)?>", k):
-                        kb += v
-                        n += 1
+                        dom[c] = dom.get(c, 0.0) + v
+                        seen_dom += c == counters[0]
                     elif any(("::" + name + "(") in k or ("::" + name + "<") in k for name in RASTER):
-                        rkb += v            # the five kernels of one mvlm_render together, per render call
-                        rn += 1 if "::tile_kernel" in k else 0
+                        ras[c] = ras.get(c, 0.0) + v
+                        seen_ras += c == counters[0] and "::tile_kernel" in k
         shutil.rmtree(out, ignore_errors=True)
-        if r.returncode != 0 or (variant_name and n == 0) or rn == 0:
-            return None, f"rocprofv3 {counter} pass gave no counters (rc {r.returncode})", None
-        total[counter] = (kb, n)
-        raster[counter] = (rkb, rn)
-    (rf_kb, rnf), (rw_kb, rnw) = raster["FETCH_SIZE"], raster["WRITE_SIZE"]
-    raster_bytes = round(2 * rf_kb * 1024 / rnf + rw_kb * 1024 / rnw)
-    if not variant_name:
-        return None, f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this invocation ({rnf} renders each)", raster_bytes
-    (f_kb, nf), (w_kb, nw) = total["FETCH_SIZE"], total["WRITE_SIZE"]
-    return (round(2 * f_kb * 1024 / nf + w_kb * 1024 / nw),
-            f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this invocation ({nf} dispatches each)", raster_bytes)
+        if r.returncode != 0 or (variant_name and seen_dom == 0) or seen_ras == 0:
+            return {"error": f"rocprofv3 {'+'.join(counters)} pass gave no counters (rc {r.returncode})"}
+        n_dom, n_ras = seen_dom, seen_ras  # (every pass runs the same number of launches)
+    res = {"raster_traffic": round((2 * ras["FETCH_SIZE"] + ras["WRITE_SIZE"]) * 1024 / n_ras),
+           "source": f"live: rocprofv3 --pmc passes of this invocation ({n_dom} dispatches of the kernel, {n_ras} renders per pass)"}
+    if variant_name:
+        res["traffic"] = round((2 * dom["FETCH_SIZE"] + dom["WRITE_SIZE"]) * 1024 / n_dom)
+        gui = dom.get("GRBM_GUI_ACTIVE", 0.0) / 8
+        res["mfma_busy"] = round(dom.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024), 4) if gui > 0 else None
+    return res
 
 
 def visible_gpus() -> int:
@@ -653,13 +657,15 @@ def main():
                 child_args += ["--views-total", str(args.views_total)]
             dom_name = cnn_ctx.lib.mvlm_conv_variant_name(max(prof, key=lambda k: prof[k][1])).decode() if prof else None
             t0 = time.time()
-            live = live_traffic(dom_name, child_args)
-            log(f"live HBM traffic: {live} ({time.time() - t0:.0f} s)")
+            live = live_counters(dom_name, child_args)
+            log(f"live counters: {live} ({time.time() - t0:.0f} s)")
+            if "error" in live:
+                live = {"why_not": live["error"]}
         roof_r = None
         if render_calls:
             avg_ms = render_ms / render_calls
             gbs = ras_bytes_view * n_local / (avg_ms * 1e-3) / 1e9
-            tr, rsrc = (live[2], live[1]) if live and live[2] is not None else committed_traffic(workload_key, "rasteriser")
+            tr, rsrc = (live["raster_traffic"], live["source"]) if live and "raster_traffic" in live else committed_traffic(workload_key, "rasteriser")
             roof_r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                       "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": tr, "traffic_source": rsrc, "kernel": "rasteriser (5 kernels of one mvlm_render)",
                       "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes_per_view": ras_bytes_view,
@@ -673,14 +679,14 @@ def main():
             total_f = sum(p[0] for p in prof.values())
             total_ms = sum(p[1] for p in prof.values())
             name = lib.mvlm_conv_variant_name(dom).decode()
-            traffic, src = (live[0], live[1]) if live else (None, None)
+            traffic, src = (live["traffic"], live["source"]) if live and "traffic" in live else (None, None)
             if traffic is None:
-                why = src
                 traffic, src = committed_traffic(workload_key, name)
-                if src and why:
-                    src = f"{src} (committed profile; live measurement unavailable: {why})"
+                if src and live and live.get("why_not"):
+                    src = f"{src} (committed profile; live measurement unavailable: {live['why_not']})"
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                    "mfma_busy": live.get("mfma_busy") if live else None,
                     "kernel": name, "kernel_avg_ms": round(t_ms / cnt, 4),
                     "kernel_launches_per_step": cnt // args.steps,
                     "kernel_share_of_conv_time": round(t_ms / total_ms, 3),
