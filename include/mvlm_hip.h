@@ -88,6 +88,25 @@ int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_ho
                      mvlm_mesh** out);
 void mvlm_mesh_free(mvlm_ctx* ctx, mvlm_mesh* mesh);
 
+/* ---- JPEG texture decoded on the device (replaces vtkJPEGReader in obj_to_actor, utils3d.py:28-34 / :42-48, and in
+ * multi_read_surface's texture lookup, utils3d.py:457-462; the decoder behind vtkJPEGReader is libjpeg-turbo with its
+ * defaults - JDCT_ISLOW, fancy upsampling, RGB out - and the bytes produced here are libjpeg's) ---------------------
+ * Taken: baseline / extended sequential Huffman JPEG (SOF0 / SOF1), 8 bit, one interleaved scan, grey or YCbCr with
+ * 1x1 / 2x1 / 2x2 luma sampling over 1x1 chroma, restart intervals.  Return code 2 = "not taken" (progressive,
+ * arithmetic, CMYK, 12 bit, other sampling, corrupt entropy-coded data; mvlm_last_error / why says which): the caller
+ * decodes such a file with libjpeg on the host and uploads the pixels with mvlm_mesh_upload. */
+/* header only, no GPU, no ctx: 0 and the size if the device decoder takes this stream, 2 and the reason in why if not */
+int mvlm_jpeg_info(const uint8_t* jpeg_host, size_t n_bytes, int* width, int* height, int* components, char* why, int why_len);
+/* mvlm_mesh_upload with the texture given as the JPEG file's bytes: headers are parsed and byte stuffing is removed on the
+ * host (into pinned staging), entropy decoding, inverse DCT, chroma upsampling and colour conversion run on the context's
+ * upload stream.  The calling thread waits for that stream (not for the launch stream) before it returns. */
+int mvlm_mesh_upload_jpeg(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                          const int32_t* tris_host, int n_tris, const uint8_t* jpeg_host, size_t jpeg_bytes,
+                          mvlm_mesh** out);
+/* the decoder alone: rgb_dev u8[H,W,3] (sizes from mvlm_jpeg_info) is complete when the call returns; rounds_out (may be
+ * NULL): how many synchronisation rounds the parallel entropy decoder needed */
+int mvlm_jpeg_decode(mvlm_ctx* ctx, const uint8_t* jpeg_host, size_t jpeg_bytes, uint8_t* rgb_dev, int* rounds_out);
+
 /* ---- render (replaces render3d.py:114-177 + :191, all poses in one launch set) --- */
 /* rot_host f64[N,9]: row-major M = Ry*Rx*Rz per view (render3d.py:140-144).
  * out_dev f32[N,256,256,4]: RGB + depth planes in [0,1], already flipped to

@@ -3,6 +3,8 @@
 #include <atomic>
 #include <cstring>
 
+#include <memory>
+
 #include "common.h"
 
 void* mvlm_ctx::get_scratch(const char* name, size_t bytes) {
@@ -68,6 +70,8 @@ extern "C" void mvlm_ctx_destroy(mvlm_ctx* ctx) {
         if (ctx->upload_stage_done[i]) hipEventDestroy(ctx->upload_stage_done[i]);
     }
     if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
+    if (ctx->jpeg_scratch) hipFree(ctx->jpeg_scratch);
+    if (ctx->jpeg_flags_host) hipHostFree(ctx->jpeg_flags_host);
     if (ctx->render_overflow_host) hipHostFree(ctx->render_overflow_host);
     for (auto e : ctx->cnn.event_pool)
         if (e) hipEventDestroy(e);
@@ -124,9 +128,11 @@ extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {
     return 0;
 }
 
-extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
-                                const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
-                                mvlm_mesh** out) {
+// jpeg != null: the texture is decoded on the device from the staged JPEG (jpeg.hip) instead of copied from tex_host;
+// returns 2 (and no mesh) when the stream turns out not to decode - the caller then decodes on the host
+static int mesh_upload_impl(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts, const int32_t* tris_host,
+                            int n_tris, const uint8_t* tex_host, int tex_h, int tex_w, MvlmJpegPlan* jpeg,
+                            const uint8_t* jpeg_bytes, size_t jpeg_n, mvlm_mesh** out) {
     // Called from reader threads while another thread launches kernels on this context.  The host work - index
     // validation (O(3T)), waiting for a staging slot, a possible hipHostMalloc, the 10-25 MB memcpy into pinned memory -
     // runs under the upload mutex only; the context mutex every launch entry point takes is held just for the pool
@@ -134,20 +140,23 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     MVLM_REQUIRE(ctx, out, "mesh_upload: null output");
     *out = nullptr;
     MVLM_REQUIRE(ctx, verts_host && tris_host && n_verts > 0 && n_tris > 0, "mesh_upload: mesh does not contain any points");
-    MVLM_REQUIRE(ctx, !tex_host || (tex_h > 0 && tex_w > 0), "mesh_upload: bad texture size");
+    MVLM_REQUIRE(ctx, !(tex_host || jpeg) || (tex_h > 0 && tex_w > 0), "mesh_upload: bad texture size");
     for (long i = 0; i < 3l * n_tris; ++i)
         MVLM_REQUIRE(ctx, tris_host[i] >= 0 && tris_host[i] < n_verts, "mesh_upload: triangle index out of range");
-    const bool with_tex = tex_host && uvs_host;
-    const void* src[4] = {verts_host, uvs_host, tris_host, with_tex ? tex_host : nullptr};
+    const bool with_tex = (tex_host || jpeg) && uvs_host;
+    if (!with_tex) jpeg = nullptr;
+    const void* src[4] = {verts_host, uvs_host, tris_host, with_tex && !jpeg ? tex_host : nullptr};
     const size_t bytes[4] = {size_t(n_verts) * 12, uvs_host ? size_t(n_verts) * 8 : 0, size_t(n_tris) * 12,
                              with_tex ? size_t(tex_h) * tex_w * 3 : 0};
     // the rasteriser fetches a texel with one 4-byte load at byte 3 * index: 4 spare bytes behind the texture
     const size_t room[4] = {bytes[0], bytes[1], bytes[2], bytes[3] ? bytes[3] + 4 : 0};
-    size_t off[4], total = 0;
+    size_t off[5], total = 0;
     for (int i = 0; i < 4; ++i) {
         off[i] = total;
-        total += (bytes[i] + 255) / 256 * 256;
+        total += ((src[i] ? bytes[i] : 0) + 255) / 256 * 256;
     }
+    off[4] = total;  // the JPEG's header, tables and unstuffed stream
+    if (jpeg) total += mvlm_jpeg_stage_bytes(*jpeg, jpeg_n);
 
     std::lock_guard<std::mutex> upload_lock(ctx->upload_mu);
     MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
@@ -166,7 +175,12 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     }
     auto* stage = static_cast<unsigned char*>(ctx->upload_stage[slot]);
     for (int i = 0; i < 4; ++i)
-        if (bytes[i]) std::memcpy(stage + off[i], src[i], bytes[i]);
+        if (src[i] && bytes[i]) std::memcpy(stage + off[i], src[i], bytes[i]);
+    std::string jpeg_why;
+    if (jpeg && mvlm_jpeg_fill_stage(*jpeg, jpeg_bytes, jpeg_n, stage + off[4], jpeg_why) != 0) {
+        ctx->fail("jpeg: " + jpeg_why);
+        return 2;
+    }
 
     auto* m = new mvlm_mesh();
     static std::atomic<unsigned long long> next_uid{1};
@@ -205,12 +219,23 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
                     ok = false;
                 }
             }
-            if (ok && hipMemcpyAsync(*dst[i], stage + off[i], bytes[i], hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) ok = false;
+            if (ok && src[i] && hipMemcpyAsync(*dst[i], stage + off[i], bytes[i], hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) ok = false;
         }
         if (with_tex) {
             m->tex_h = tex_h;
             m->tex_w = tex_w;
         }
+    }
+    int jpeg_rc = 0;
+    if (ok && jpeg) {
+        // decode kernels on the upload stream; the host waits for that stream twice (jpeg.hip), with only the upload mutex
+        // held - the launch thread keeps going
+        jpeg_rc = mvlm_jpeg_run(ctx, *jpeg, stage + off[4], m->tex, ctx->upload_stream, jpeg_why, nullptr);
+        if (jpeg_rc == 2) ctx->fail("jpeg: " + jpeg_why);
+        if (jpeg_rc != 0) ok = false;
+    }
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
         if (ok) {
             if (!ctx->upload_stage_done[slot]) ctx->upload_stage_done[slot] = ctx->take_event();
             m->ready = ctx->take_event();
@@ -222,10 +247,89 @@ extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const fl
     if (!ok) {
         (void)hipStreamSynchronize(ctx->upload_stream);
         mvlm_mesh_free(nullptr, m);
+        if (jpeg_rc != 0) return jpeg_rc;  // (the message is set)
         return ctx->fail("mesh_upload: device allocation / copy failed");
     }
     *out = m;
     return 0;
+}
+
+extern "C" int mvlm_mesh_upload(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                                const int32_t* tris_host, int n_tris, const uint8_t* tex_host, int tex_h, int tex_w,
+                                mvlm_mesh** out) {
+    return mesh_upload_impl(ctx, verts_host, uvs_host, n_verts, tris_host, n_tris, tex_host, tex_h, tex_w, nullptr, nullptr, 0, out);
+}
+
+// ---- JPEG textures decoded on the device (jpeg.hip) ------------------------------------------------------------------
+extern "C" int mvlm_jpeg_info(const uint8_t* jpeg, size_t n_bytes, int* width, int* height, int* components, char* why, int why_len) {
+    MvlmJpegPlan* plan = mvlm_jpeg_plan_new();
+    std::string w;
+    const int rc = mvlm_jpeg_plan_impl(jpeg, n_bytes, *plan, w);
+    if (rc == 0) mvlm_jpeg_plan_dims(*plan, width, height, components);
+    if (why && why_len > 0) {
+        std::snprintf(why, size_t(why_len), "%s", w.c_str());
+    }
+    mvlm_jpeg_plan_delete(plan);
+    return rc;
+}
+
+extern "C" int mvlm_mesh_upload_jpeg(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                                     const int32_t* tris_host, int n_tris, const uint8_t* jpeg, size_t jpeg_bytes, mvlm_mesh** out) {
+    MVLM_REQUIRE(ctx, out, "mesh_upload_jpeg: null output");
+    *out = nullptr;
+    MVLM_REQUIRE(ctx, jpeg && jpeg_bytes > 0, "mesh_upload_jpeg: no JPEG");
+    std::unique_ptr<MvlmJpegPlan, void (*)(MvlmJpegPlan*)> plan(mvlm_jpeg_plan_new(), mvlm_jpeg_plan_delete);
+    std::string w;
+    if (mvlm_jpeg_plan_impl(jpeg, jpeg_bytes, *plan, w) != 0) {
+        ctx->fail("jpeg: " + w);
+        return 2;
+    }
+    int tw = 0, th = 0, nc = 0;
+    mvlm_jpeg_plan_dims(*plan, &tw, &th, &nc);
+    return mesh_upload_impl(ctx, verts_host, uvs_host, n_verts, tris_host, n_tris, nullptr, th, tw, plan.get(), jpeg, jpeg_bytes, out);
+}
+
+// the decoder alone (tests, tools): rgb_dev [H, W, 3] is complete on return; rounds_out: synchronisation rounds it took
+extern "C" int mvlm_jpeg_decode(mvlm_ctx* ctx, const uint8_t* jpeg, size_t jpeg_bytes, uint8_t* rgb_dev, int* rounds_out) {
+    MVLM_REQUIRE(ctx, jpeg && jpeg_bytes > 0 && rgb_dev, "jpeg_decode: null pointer");
+    std::unique_ptr<MvlmJpegPlan, void (*)(MvlmJpegPlan*)> plan(mvlm_jpeg_plan_new(), mvlm_jpeg_plan_delete);
+    std::string w;
+    if (mvlm_jpeg_plan_impl(jpeg, jpeg_bytes, *plan, w) != 0) {
+        ctx->fail("jpeg: " + w);
+        return 2;
+    }
+    std::lock_guard<std::mutex> upload_lock(ctx->upload_mu);
+    MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->upload_stream) MVLM_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    const size_t total = mvlm_jpeg_stage_bytes(*plan, jpeg_bytes);
+    const int slot = ctx->upload_stage_next;
+    ctx->upload_stage_next ^= 1;
+    if (ctx->upload_stage_done[slot]) MVLM_CHECK_HIP(ctx, hipEventSynchronize(ctx->upload_stage_done[slot]));
+    if (ctx->upload_stage_cap[slot] < total) {
+        if (ctx->upload_stage[slot]) (void)hipHostFree(ctx->upload_stage[slot]);
+        ctx->upload_stage[slot] = nullptr;
+        ctx->upload_stage_cap[slot] = 0;
+        const size_t cap = (total + (size_t(4) << 20)) / (size_t(4) << 20) * (size_t(4) << 20);
+        MVLM_CHECK_HIP(ctx, hipHostMalloc(&ctx->upload_stage[slot], cap, hipHostMallocDefault));
+        ctx->upload_stage_cap[slot] = cap;
+    }
+    auto* stage = static_cast<unsigned char*>(ctx->upload_stage[slot]);
+    if (mvlm_jpeg_fill_stage(*plan, jpeg, jpeg_bytes, stage, w) != 0) {
+        ctx->fail("jpeg: " + w);
+        return 2;
+    }
+    // whatever the launch stream still does with rgb_dev comes first
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        hipEvent_t e = ctx->take_event();
+        MVLM_REQUIRE(ctx, e, "jpeg_decode: no event");
+        const bool ok = hipEventRecord(e, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->upload_stream, e, 0) == hipSuccess;
+        ctx->event_free.push_back(e);
+        MVLM_REQUIRE(ctx, ok, "jpeg_decode: stream order");
+    }
+    const int rc = mvlm_jpeg_run(ctx, *plan, stage, rgb_dev, ctx->upload_stream, w, rounds_out);
+    if (rc == 2) ctx->fail("jpeg: " + w);
+    return rc;  // (mvlm_jpeg_run has waited for the stream: the staging slot is free, the image complete)
 }
 
 // Buffers go back to the context's pool together with an event on the launch stream: whatever was enqueued for this

@@ -264,6 +264,10 @@ struct mvlm_ctx {
     size_t upload_stage_cap[2] = {0, 0};
     hipEvent_t upload_stage_done[2] = {nullptr, nullptr};
     int upload_stage_next = 0;
+    // JPEG textures decoded on the device (jpeg.hip): scratch of the upload path, guarded by upload_mu
+    void* jpeg_scratch = nullptr;
+    size_t jpeg_scratch_cap = 0;
+    int32_t* jpeg_flags_host = nullptr;  // pinned
     std::vector<hipEvent_t> event_free;  // recycled (timing-disabled) events
     hipEvent_t take_event() {
         if (!event_free.empty()) {
@@ -311,6 +315,17 @@ inline int mvlm_mesh_wait_ready(mvlm_ctx* ctx, const mvlm_mesh* m, hipStream_t s
     if (m->ready && hipStreamWaitEvent(stream, m->ready, 0) != hipSuccess) return ctx->fail("mesh: hipStreamWaitEvent failed");
     return 0;
 }
+
+// jpeg.hip
+struct MvlmJpegPlan;
+int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::string& why);
+void mvlm_jpeg_plan_dims(const MvlmJpegPlan& plan, int* width, int* height, int* components);
+MvlmJpegPlan* mvlm_jpeg_plan_new();
+void mvlm_jpeg_plan_delete(MvlmJpegPlan* p);
+size_t mvlm_jpeg_stage_bytes(const MvlmJpegPlan& plan, size_t n);
+int mvlm_jpeg_fill_stage(MvlmJpegPlan& plan, const uint8_t* data, size_t n, uint8_t* stage, std::string& why);
+int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned, uint8_t* rgb_dev, hipStream_t stream,
+                  std::string& why, int* rounds_out);
 
 // conv_mfma.hip
 constexpr long MVLM_KPARTS_MAX_TILES = 2048;  // output tiles of a launch that divides K over workgroups

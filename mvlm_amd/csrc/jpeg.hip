@@ -1,0 +1,845 @@
+// Baseline JPEG -> RGB texture on the GPU (the texture half of the reference's mesh ingest: vtkJPEGReader in
+// src/mvlm/utils/utils3d.py:28-34 / :42-48 / :457-462; the decoder behind it is libjpeg-turbo inside VTK - JDCT_ISLOW,
+// fancy upsampling, JCS_RGB).  Results are byte for byte libjpeg's (oracle/jpeg.py restates the arithmetic; the tests pin
+// both against Pillow's libjpeg-turbo).
+//
+// Huffman decoding is serial per restart interval, 16 ms of one core for a 2048 x 2048 texture.  Here the entropy-coded
+// segment is cut into 1024-bit subsequences, one thread each.  A thread needs the decoder state at its first bit (bit
+// offset of the first whole symbol, block within the MCU, zigzag index); it starts from a guess, and because Huffman codes
+// self-synchronise the state it reaches at its END is soon the true one whatever it started from.  Rounds of "decode my
+// subsequence from the state my predecessor ended in" run until a whole round changes no state - then every state is the
+// true one BY CONSTRUCTION (the first subsequence of every restart interval starts from the known state, the rest follows
+// by induction), however many rounds that took; a thread whose start state did not change since the last round keeps its
+// stored result.  A segmented prefix sum over the subsequences' block counts and DC-difference sums then tells every
+// thread where its coefficients go and what its DC predictors are, one more pass writes the coefficients, and the inverse
+// DCT, the chroma upsampling and the colour conversion are plain data-parallel kernels.
+//
+// Scope: SOF0 / SOF1, 8 bit, one interleaved scan, grey or YCbCr with 1x1 / 2x1 / 2x2 luma over 1x1 chroma, restart
+// intervals.  Everything else is reported as "not taken" (return code 2) and the caller decodes with libjpeg on the host.
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+
+constexpr int SUB_WORDS = 32;               // 32-bit words per subsequence
+constexpr int SUB_BITS = SUB_WORDS * 32;    // 1024
+constexpr int SUB_BYTES = SUB_WORDS * 4;    // 128
+constexpr int DEC_WG = 64;                  // subsequences (= threads) per workgroup of the decode kernels
+constexpr int DEC_PITCH = DEC_WG + 1;       // LDS row pitch of the transposed stream words (odd: no bank pattern)
+constexpr int LUT_BITS = 9;
+constexpr int N_SLOTS = 6;                  // Huffman tables on the device: DC of component c in slot c, AC in slot 3 + c
+constexpr int ROUNDS_PER_BATCH = 24;
+constexpr int MAX_ROUNDS = 480;
+constexpr uint32_t STATE_DEAD = 0x80000000u;
+
+const uint8_t kNatural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// what the kernels read (built on the host, copied with the stream)
+struct JpegDev {
+    int width, height, ncomp, hmax, vmax, mcus_x, mcus_y, bpm;
+    int n_sub, total_blocks, seg_blocks, fancy;
+    int blk_comp[8], blk_bx[8], blk_by[8];
+    int plane_w[3], plane_h[3], real_w[3], real_h[3], plane_off[3];
+    uint16_t quant[3][64];                 // natural order
+    uint16_t lut[N_SLOTS][1 << LUT_BITS];  // length << 8 | symbol for codes of at most LUT_BITS bits, else 0
+    int32_t maxcode[N_SLOTS][17];          // [length]: the largest code of that length, -1 if none
+    int32_t valoff[N_SLOTS][17];           // [length]: index of its first symbol minus its smallest code
+    uint8_t vals[N_SLOTS][256];
+    uint8_t nat[64];
+};
+
+struct HuffHost {
+    bool have = false;
+    uint8_t counts[16];
+    uint8_t vals[256];
+    int n = 0;
+};
+
+}  // namespace
+
+struct MvlmJpegPlan {
+    JpegDev dev;
+    int ri = 0, n_seg = 0;
+    size_t scan_begin = 0;
+    size_t n_mcus = 0;
+    // after mvlm_jpeg_fill_stage
+    size_t off_stream = 0, stream_bytes = 0, off_subseg = 0, stage_used = 0;
+};
+
+namespace {
+
+inline int rd16(const uint8_t* p) { return (int(p[0]) << 8) | p[1]; }
+
+void build_slot(JpegDev& d, int slot, const HuffHost& h) {
+    std::memset(d.lut[slot], 0, sizeof(d.lut[slot]));
+    std::memcpy(d.vals[slot], h.vals, 256);
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        const int n = h.counts[len - 1];
+        d.valoff[slot][len] = k - code;
+        for (int i = 0; i < n; ++i, ++code, ++k) {
+            if (len <= LUT_BITS) {
+                const int first = code << (LUT_BITS - len);
+                for (int f = 0; f < (1 << (LUT_BITS - len)); ++f) d.lut[slot][first + f] = uint16_t((len << 8) | h.vals[k]);
+            }
+        }
+        d.maxcode[slot][len] = n ? code - 1 : -1;
+        code <<= 1;
+    }
+    d.maxcode[slot][0] = -1;
+    d.valoff[slot][0] = 0;
+}
+
+}  // namespace
+
+// 0: a JPEG the device decoder takes; 2: not taken (why says which rule); never touches the GPU
+int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::string& why) {
+    if (!data || n < 4 || data[0] != 0xFF || data[1] != 0xD8) {
+        why = "not a JPEG stream";
+        return 2;
+    }
+    JpegDev& d = plan.dev;
+    std::memset(&d, 0, sizeof(d));
+    uint16_t quant[4][64];
+    bool have_q[4] = {false, false, false, false};
+    HuffHost huff[2][4];
+    int comp_id[3] = {0, 0, 0}, comp_h[3] = {1, 1, 1}, comp_v[3] = {1, 1, 1}, comp_tq[3] = {0, 0, 0}, comp_td[3], comp_ta[3];
+    bool have_frame = false, jfif = false;
+    int adobe = -1;
+    size_t p = 2;
+    for (;;) {
+        while (p < n && data[p] != 0xFF) ++p;
+        while (p < n && data[p] == 0xFF) ++p;
+        if (p >= n) {
+            why = "no scan";
+            return 2;
+        }
+        const int m = data[p++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9 || p + 2 > n) {
+            why = "no scan";
+            return 2;
+        }
+        const size_t len = size_t(rd16(data + p));
+        if (len < 2 || p + len > n) {
+            why = "truncated segment";
+            return 2;
+        }
+        const uint8_t* seg = data + p + 2;
+        const size_t sl = len - 2;
+        p += len;
+        if (m == 0xDB) {
+            size_t q = 0;
+            while (q < sl) {
+                const int pq = seg[q] >> 4, tq = seg[q] & 15;
+                ++q;
+                if (tq > 3 || q + (pq ? 128 : 64) > sl) {
+                    why = "bad DQT";
+                    return 2;
+                }
+                for (int i = 0; i < 64; ++i) {
+                    quant[tq][kNatural[i]] = pq ? uint16_t(rd16(seg + q + 2 * i)) : seg[q + i];
+                }
+                q += pq ? 128 : 64;
+                have_q[tq] = true;
+            }
+        } else if (m == 0xC4) {
+            size_t q = 0;
+            while (q < sl) {
+                if (q + 17 > sl) {
+                    why = "bad DHT";
+                    return 2;
+                }
+                const int tc = seg[q] >> 4, th = seg[q] & 15;
+                int cnt = 0;
+                for (int i = 0; i < 16; ++i) cnt += seg[q + 1 + i];
+                if (tc > 1 || th > 3 || cnt > 256 || q + 17 + size_t(cnt) > sl) {
+                    why = "bad DHT";
+                    return 2;
+                }
+                HuffHost& h = huff[tc][th];
+                h.have = true;
+                h.n = cnt;
+                std::memcpy(h.counts, seg + q + 1, 16);
+                std::memset(h.vals, 0, 256);
+                std::memcpy(h.vals, seg + q + 17, size_t(cnt));
+                // the codes must fit their lengths (Kraft): a table that over-subscribes a length is corrupt
+                long code = 0;
+                for (int l = 1; l <= 16; ++l) {
+                    code += h.counts[l - 1];
+                    if (code > (1l << l)) {
+                        why = "bad DHT";
+                        return 2;
+                    }
+                    code <<= 1;
+                }
+                q += 17 + size_t(cnt);
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || seg[0] != 8) {
+                why = "sample precision other than 8 bit";
+                return 2;
+            }
+            d.height = rd16(seg + 1);
+            d.width = rd16(seg + 3);
+            d.ncomp = seg[5];
+            if ((d.ncomp != 1 && d.ncomp != 3) || sl < size_t(6 + 3 * d.ncomp)) {
+                why = "component count other than 1 or 3";
+                return 2;
+            }
+            for (int i = 0; i < d.ncomp; ++i) {
+                comp_id[i] = seg[6 + 3 * i];
+                comp_h[i] = seg[7 + 3 * i] >> 4;
+                comp_v[i] = seg[7 + 3 * i] & 15;
+                comp_tq[i] = seg[8 + 3 * i];
+            }
+            have_frame = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            why = "progressive / lossless / arithmetic JPEG";
+            return 2;
+        } else if (m == 0xDD) {
+            if (sl < 2) {
+                why = "bad DRI";
+                return 2;
+            }
+            plan.ri = rd16(seg);
+        } else if (m == 0xE0 && sl >= 5 && std::memcmp(seg, "JFIF\0", 5) == 0) {
+            jfif = true;
+        } else if (m == 0xEE && sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0) {
+            adobe = seg[11];
+        } else if (m == 0xDA) {
+            if (!have_frame || sl < 1 || seg[0] != d.ncomp || sl < size_t(4 + 2 * d.ncomp)) {
+                why = "a scan that does not hold every component";
+                return 2;
+            }
+            for (int i = 0; i < d.ncomp; ++i) {
+                if (seg[1 + 2 * i] != comp_id[i]) {
+                    why = "scan components out of frame order";
+                    return 2;
+                }
+                comp_td[i] = seg[2 + 2 * i] >> 4;
+                comp_ta[i] = seg[2 + 2 * i] & 15;
+            }
+            if (seg[1 + 2 * d.ncomp] != 0 || seg[2 + 2 * d.ncomp] != 63 || seg[3 + 2 * d.ncomp] != 0) {
+                why = "spectral selection / successive approximation in a sequential scan";
+                return 2;
+            }
+            break;
+        }
+    }
+    if (d.width <= 0 || d.height <= 0) {
+        why = "empty frame";
+        return 2;
+    }
+    if (d.ncomp == 3) {
+        bool ycc;  // jdapimin.c default_decompress_parms
+        if (jfif)
+            ycc = true;
+        else if (adobe >= 0)
+            ycc = adobe != 0;
+        else
+            ycc = !(comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B');
+        if (!ycc) {
+            why = "three components that are not YCbCr";
+            return 2;
+        }
+        const bool luma_ok = (comp_h[0] == 1 && comp_v[0] == 1) || (comp_h[0] == 2 && comp_v[0] == 1) || (comp_h[0] == 2 && comp_v[0] == 2);
+        if (!luma_ok || comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) {
+            why = "sampling factors other than 1x1 / 2x1 / 2x2 luma over 1x1 chroma";
+            return 2;
+        }
+    } else {
+        comp_h[0] = comp_v[0] = 1;
+    }
+    d.hmax = comp_h[0];
+    d.vmax = comp_v[0];
+    d.mcus_x = (d.width + 8 * d.hmax - 1) / (8 * d.hmax);
+    d.mcus_y = (d.height + 8 * d.vmax - 1) / (8 * d.vmax);
+    d.bpm = 0;
+    int off = 0;
+    for (int c = 0; c < d.ncomp; ++c) {
+        if (comp_tq[c] > 3 || !have_q[comp_tq[c]] || comp_td[c] > 3 || comp_ta[c] > 3 || !huff[0][comp_td[c]].have || !huff[1][comp_ta[c]].have) {
+            why = "a table the scan names is missing";
+            return 2;
+        }
+        std::memcpy(d.quant[c], quant[comp_tq[c]], sizeof(d.quant[c]));
+        build_slot(d, c, huff[0][comp_td[c]]);
+        build_slot(d, 3 + c, huff[1][comp_ta[c]]);
+        for (int by = 0; by < comp_v[c]; ++by)
+            for (int bx = 0; bx < comp_h[c]; ++bx) {
+                d.blk_comp[d.bpm] = c;
+                d.blk_bx[d.bpm] = bx;
+                d.blk_by[d.bpm] = by;
+                ++d.bpm;
+            }
+        d.plane_w[c] = d.mcus_x * comp_h[c] * 8;
+        d.plane_h[c] = d.mcus_y * comp_v[c] * 8;
+        d.real_w[c] = (d.width * comp_h[c] + d.hmax - 1) / d.hmax;
+        d.real_h[c] = (d.height * comp_v[c] + d.vmax - 1) / d.vmax;
+        d.plane_off[c] = off;
+        off += d.plane_w[c] * d.plane_h[c];
+    }
+    for (int c = d.ncomp; c < 3; ++c) {  // unused slots: every code invalid
+        for (int s : {c, 3 + c})
+            for (int l = 0; l <= 16; ++l) d.maxcode[s][l] = -1;
+    }
+    std::memcpy(d.nat, kNatural, 64);
+    plan.n_mcus = size_t(d.mcus_x) * d.mcus_y;
+    if (plan.n_mcus * d.bpm > (size_t(1) << 26)) {
+        why = "image too large";
+        return 2;
+    }
+    d.total_blocks = int(plan.n_mcus * d.bpm);
+    plan.n_seg = plan.ri ? int((plan.n_mcus + plan.ri - 1) / plan.ri) : 1;
+    d.seg_blocks = plan.ri ? plan.ri * d.bpm : d.total_blocks;
+    d.fancy = (d.ncomp == 3 && d.hmax == 2 && d.real_w[1] > 2) ? 1 : 0;  // jdsample.c: fancy only when downsampled_width > 2
+    plan.scan_begin = p;
+    return 0;
+}
+
+MvlmJpegPlan* mvlm_jpeg_plan_new() { return new MvlmJpegPlan(); }
+void mvlm_jpeg_plan_delete(MvlmJpegPlan* p) { delete p; }
+void mvlm_jpeg_plan_dims(const MvlmJpegPlan& plan, int* width, int* height, int* components) {
+    if (width) *width = plan.dev.width;
+    if (height) *height = plan.dev.height;
+    if (components) *components = plan.dev.ncomp;
+}
+
+// upper bound of what mvlm_jpeg_fill_stage writes
+size_t mvlm_jpeg_stage_bytes(const MvlmJpegPlan& plan, size_t n) {
+    const size_t stream = (n - plan.scan_begin) + size_t(plan.n_seg) * SUB_BYTES + 4 * SUB_BYTES;
+    return 256 + (sizeof(JpegDev) + 255) / 256 * 256 + (stream + 255) / 256 * 256 + (stream / SUB_BYTES + 8) * 4;
+}
+
+// header + stream without byte stuffing (every restart interval starts on a subsequence boundary, padded with 1-bits) +
+// restart interval of every subsequence.  0: ok; 2: the markers in the entropy-coded segment are not what the header says
+int mvlm_jpeg_fill_stage(MvlmJpegPlan& plan, const uint8_t* data, size_t n, uint8_t* stage, std::string& why) {
+    const size_t off_hdr = 0;
+    plan.off_stream = (sizeof(JpegDev) + 255) / 256 * 256;
+    uint8_t* out = stage + plan.off_stream;
+    size_t o = 0;
+    size_t p = plan.scan_begin;
+    int seg = 0;
+    std::vector<int32_t> seg_first;  // first subsequence of every restart interval
+    seg_first.push_back(0);
+    for (;;) {
+        const uint8_t* q = p < n ? static_cast<const uint8_t*>(std::memchr(data + p, 0xFF, n - p)) : nullptr;
+        if (!q || size_t(q - data) + 1 >= n) {
+            std::memcpy(out + o, data + p, n - p);  // (a stream that ends without EOI: libjpeg also decodes what is there)
+            o += n - p;
+            break;
+        }
+        const size_t run = size_t(q - (data + p));
+        std::memcpy(out + o, data + p, run);
+        o += run;
+        const int nxt = q[1];
+        p = size_t(q - data);
+        if (nxt == 0) {
+            out[o++] = 0xFF;
+            p += 2;
+        } else if (nxt >= 0xD0 && nxt <= 0xD7) {
+            if (++seg >= plan.n_seg) {
+                why = "more restart markers than restart intervals";
+                return 2;
+            }
+            const size_t pad = (SUB_BYTES - o % SUB_BYTES) % SUB_BYTES;
+            std::memset(out + o, 0xFF, pad);
+            o += pad;
+            seg_first.push_back(int32_t(o / SUB_BYTES));
+            p += 2;
+        } else if (nxt == 0xFF) {
+            p += 1;
+        } else {
+            break;  // EOI (or any other marker): the scan ends here
+        }
+    }
+    if (seg + 1 != plan.n_seg) {
+        why = "fewer restart markers than restart intervals";
+        return 2;
+    }
+    const size_t pad = (SUB_BYTES - o % SUB_BYTES) % SUB_BYTES + 2 * SUB_BYTES;
+    std::memset(out + o, 0xFF, pad);
+    o += pad;
+    plan.stream_bytes = o;
+    plan.dev.n_sub = int(o / SUB_BYTES) - 2;  // (the two subsequences of fill are only ever read, never decoded)
+    if (plan.dev.n_sub <= 0) {
+        why = "empty scan";
+        return 2;
+    }
+    plan.off_subseg = plan.off_stream + (o + 255) / 256 * 256;
+    auto* sub_seg = reinterpret_cast<int32_t*>(stage + plan.off_subseg);
+    seg_first.push_back(plan.dev.n_sub);
+    for (int g = 0; g < plan.n_seg; ++g)
+        for (int s = seg_first[size_t(g)]; s < seg_first[size_t(g) + 1]; ++s) sub_seg[s] = g;
+    plan.stage_used = plan.off_subseg + size_t(plan.dev.n_sub) * 4;
+    std::memcpy(stage + off_hdr, &plan.dev, sizeof(JpegDev));
+    return 0;
+}
+
+namespace {
+
+struct DecLds {
+    uint32_t words[SUB_WORDS * DEC_PITCH];
+    uint16_t lut[N_SLOTS][1 << LUT_BITS];
+    int32_t maxcode[N_SLOTS][17];
+    int32_t valoff[N_SLOTS][17];
+    uint8_t vals[N_SLOTS][256];
+    uint8_t nat[64];
+    int blk_comp[8];
+};
+
+__device__ inline void dec_stage(DecLds& L, const JpegDev* hdr, const uint32_t* stream, long total_words, int sub0) {
+    const int t = threadIdx.x;
+    // this workgroup's DEC_WG subsequences and the one behind them, word j of subsequence c at [j][c]
+    const long w0 = long(sub0) * SUB_WORDS;
+    for (int i = t; i < SUB_WORDS * DEC_PITCH; i += DEC_WG) {
+        const long g = w0 + i;
+        const uint32_t v = g < total_words ? stream[g] : 0xFFFFFFFFu;
+        L.words[(i % SUB_WORDS) * DEC_PITCH + i / SUB_WORDS] = __builtin_bswap32(v);
+    }
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(hdr->lut);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(L.lut);
+    constexpr int TAB_WORDS = (sizeof(L.lut) + sizeof(L.maxcode) + sizeof(L.valoff) + sizeof(L.vals) + sizeof(L.nat)) / 4;
+    static_assert(offsetof(DecLds, nat) - offsetof(DecLds, lut) == offsetof(JpegDev, nat) - offsetof(JpegDev, lut), "table layout");
+    for (int i = t; i < TAB_WORDS; i += DEC_WG) dst[i] = src[i];
+    if (t < 8) L.blk_comp[t] = hdr->blk_comp[t];
+    __syncthreads();
+}
+
+// One subsequence from the state `in` (bit offset | block in MCU << 8 | zigzag index << 16) to the first symbol that
+// starts behind its last bit.  WRITE: the coefficients go to coef (absolute block `ablk`, at most up to `blk_limit`),
+// dc[] are the running predictors; otherwise dc[] collects the sums of the DC differences and n_blk the blocks completed.
+template <bool WRITE>
+__device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, int bpm, int& n_blk, int dc[3], int16_t* coef,
+                                           long ablk, long blk_limit) {
+    int pos = int(in & 0xFF), blk = int((in >> 8) & 0xFF), k = int((in >> 16) & 0xFF);
+    auto word = [&](int j) { return L.words[(j & (SUB_WORDS - 1)) * DEC_PITCH + t + (j >> 5)]; };
+    int w0 = pos >> 5;
+    uint32_t hi = word(w0), lo = word(w0 + 1);
+    n_blk = 0;
+    bool dead = false;
+    if (WRITE && ablk >= blk_limit) return STATE_DEAD;
+    while (pos < SUB_BITS) {
+        const int w = pos >> 5;
+        if (w != w0) {
+            hi = lo;
+            lo = word(w + 1);
+            w0 = w;
+        }
+        const uint32_t peek = uint32_t((((uint64_t(hi) << 32) | lo) << (pos & 31)) >> 32);
+        const int comp = L.blk_comp[blk];
+        const int slot = k == 0 ? comp : 3 + comp;
+        const uint32_t e = L.lut[slot][peek >> (32 - LUT_BITS)];
+        int len = int(e >> 8), sym = int(e & 255);
+        if (len == 0) {
+            for (len = LUT_BITS + 1; len <= 16; ++len) {
+                const int code = int(peek >> (32 - len));
+                if (code <= L.maxcode[slot][len]) {
+                    sym = L.vals[slot][(code + L.valoff[slot][len]) & 255];
+                    break;
+                }
+            }
+            if (len > 16) {
+                dead = true;
+                break;
+            }
+        }
+        const int s = sym & 15;
+        int val = 0;
+        if (s) {
+            const int bits = int((peek << len) >> (32 - s));
+            val = bits < (1 << (s - 1)) ? bits - (1 << s) + 1 : bits;
+        }
+        pos += len + s;
+        if (k == 0) {
+            dc[comp] += val;
+            if (WRITE) coef[ablk * 64] = int16_t(dc[comp]);
+            k = 1;
+        } else if (s == 0) {
+            k = (sym >> 4) == 15 ? k + 16 : 64;
+        } else {
+            k += sym >> 4;
+            if (WRITE && k < 64) coef[ablk * 64 + L.nat[k]] = int16_t(val);
+            ++k;
+        }
+        if (k >= 64) {
+            k = 0;
+            blk = blk + 1 == bpm ? 0 : blk + 1;
+            ++n_blk;
+            if (WRITE && ++ablk >= blk_limit) return STATE_DEAD;
+        }
+    }
+    if (dead) return STATE_DEAD;
+    return uint32_t(pos - SUB_BITS) | (uint32_t(blk) << 8) | (uint32_t(k) << 16);
+}
+
+__global__ __launch_bounds__(DEC_WG) void jpeg_sync_kernel(const JpegDev* hdr, const uint32_t* stream, long total_words,
+                                                          const int32_t* sub_seg, const uint32_t* in_prev, const uint32_t* in_cur,
+                                                          uint32_t* in_next, uint32_t* out_state, int32_t* out_nblk, int32_t* out_dc,
+                                                          int32_t* changed, int round) {
+    if (round > 0 && changed[round - 1] == 0) return;  // the round before changed nothing: every state is final
+    __shared__ DecLds L;
+    const int sub0 = blockIdx.x * DEC_WG;
+    const int n_sub = hdr->n_sub;
+    const int t = threadIdx.x, s = sub0 + t;
+    // does any thread of this workgroup have to decode?
+    const bool mine = s < n_sub;
+    const uint32_t in = mine ? in_cur[s] : 0;
+    const bool need = mine && (round == 0 || in != in_prev[s]);
+    if (__syncthreads_or(need)) {
+        dec_stage(L, hdr, stream, total_words, sub0);
+        if (need) {
+            int n_blk, dc[3] = {0, 0, 0};
+            const uint32_t o = dec_subsequence<false>(L, t, in, hdr->bpm, n_blk, dc, nullptr, 0, 0);
+            out_state[s] = o;
+            out_nblk[s] = n_blk;
+            out_dc[3 * s] = dc[0];
+            out_dc[3 * s + 1] = dc[1];
+            out_dc[3 * s + 2] = dc[2];
+        }
+    }
+    if (!mine) return;
+    const int g = sub_seg[s];
+    if (s == 0 || sub_seg[s - 1] != g) in_next[s] = 0;  // the first subsequence of a restart interval: the known state
+    if (s + 1 < n_sub && sub_seg[s + 1] == g) {
+        const uint32_t o = out_state[s];
+        const uint32_t cur = in_cur[s + 1];
+        const uint32_t nxt = (o & STATE_DEAD) ? cur : o;
+        in_next[s + 1] = nxt;
+        if (nxt != cur) atomicOr(&changed[round], 1);
+    }
+}
+
+// segmented exclusive prefix sums over the subsequences of every restart interval: blocks completed and DC-difference
+// sums before each subsequence; one workgroup.  short_flag: a restart interval that holds fewer blocks than it must.
+__global__ __launch_bounds__(1024) void jpeg_scan_kernel(const JpegDev* hdr, const int32_t* sub_seg, const int32_t* out_nblk,
+                                                        const int32_t* out_dc, int32_t* base, int32_t* short_flag, int n_seg) {
+    __shared__ int f[1024];
+    __shared__ int v[1024][4];
+    const int n_sub = hdr->n_sub, t = threadIdx.x;
+    const int per = (n_sub + 1023) / 1024;
+    const int s0 = t * per, s1 = min(n_sub, s0 + per);
+    int acc[4] = {0, 0, 0, 0};
+    int flag = 0;
+    for (int s = s0; s < s1; ++s) {
+        if (s == 0 || sub_seg[s] != sub_seg[s - 1]) {
+            flag = 1;
+            acc[0] = acc[1] = acc[2] = acc[3] = 0;
+        }
+        acc[0] += out_nblk[s];
+        acc[1] += out_dc[3 * s];
+        acc[2] += out_dc[3 * s + 1];
+        acc[3] += out_dc[3 * s + 2];
+    }
+    f[t] = flag;
+    for (int i = 0; i < 4; ++i) v[t][i] = acc[i];
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // inclusive segmented scan: (f1, v1) + (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2)
+        int pf = 0, pv[4] = {0, 0, 0, 0};
+        const bool has = t >= d;
+        if (has) {
+            pf = f[t - d];
+            for (int i = 0; i < 4; ++i) pv[i] = v[t - d][i];
+        }
+        __syncthreads();
+        if (has) {
+            if (!f[t])
+                for (int i = 0; i < 4; ++i) v[t][i] += pv[i];
+            f[t] |= pf;
+        }
+        __syncthreads();
+    }
+    int run[4] = {0, 0, 0, 0};
+    if (t > 0)
+        for (int i = 0; i < 4; ++i) run[i] = v[t - 1][i];
+    for (int s = s0; s < s1; ++s) {
+        const int g = sub_seg[s];
+        if (s == 0 || g != sub_seg[s - 1]) run[0] = run[1] = run[2] = run[3] = 0;
+        for (int i = 0; i < 4; ++i) base[4 * s + i] = run[i];
+        run[0] += out_nblk[s];
+        run[1] += out_dc[3 * s];
+        run[2] += out_dc[3 * s + 1];
+        run[3] += out_dc[3 * s + 2];
+        if (s + 1 == n_sub || sub_seg[s + 1] != g) {
+            const long want = min(long(hdr->seg_blocks), long(hdr->total_blocks) - long(g) * hdr->seg_blocks);
+            if (run[0] < want) atomicOr(short_flag, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(DEC_WG) void jpeg_write_kernel(const JpegDev* hdr, const uint32_t* stream, long total_words,
+                                                           const int32_t* sub_seg, const uint32_t* in_state, const int32_t* base,
+                                                           int16_t* coef) {
+    __shared__ DecLds L;
+    const int sub0 = blockIdx.x * DEC_WG;
+    dec_stage(L, hdr, stream, total_words, sub0);
+    const int t = threadIdx.x, s = sub0 + t;
+    if (s >= hdr->n_sub) return;
+    const long seg0 = long(sub_seg[s]) * hdr->seg_blocks;
+    const long limit = min(seg0 + hdr->seg_blocks, long(hdr->total_blocks));
+    int n_blk, dc[3] = {base[4 * s + 1], base[4 * s + 2], base[4 * s + 3]};
+    (void)dec_subsequence<true>(L, t, in_state[s], hdr->bpm, n_blk, dc, coef, seg0 + base[4 * s], limit);
+}
+
+// jidctint.c jpeg_idct_islow in 32-bit integers: one pass over eight values, DESCALE by SHIFT
+template <int SHIFT>
+__device__ inline void idct8(const int x[8], int y[8]) {
+    int z1 = (x[2] + x[6]) * 4433;
+    const int tmp2 = z1 - x[6] * 15137;
+    const int tmp3 = z1 + x[2] * 6270;
+    const int tmp0 = (x[0] + x[4]) * 8192;
+    const int tmp1 = (x[0] - x[4]) * 8192;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int t0 = x[7], t1 = x[5], t2 = x[3], t3 = x[1];
+    z1 = t0 + t3;
+    int z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+    const int z5 = (z3 + z4) * 9633;
+    t0 *= 2446;
+    t1 *= 16819;
+    t2 *= 25172;
+    t3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 = z3 * -16069 + z5;
+    z4 = z4 * -3196 + z5;
+    t0 += z1 + z3;
+    t1 += z2 + z4;
+    t2 += z2 + z3;
+    t3 += z1 + z4;
+    constexpr int H = 1 << (SHIFT - 1);
+    y[0] = (tmp10 + t3 + H) >> SHIFT;
+    y[7] = (tmp10 - t3 + H) >> SHIFT;
+    y[1] = (tmp11 + t2 + H) >> SHIFT;
+    y[6] = (tmp11 - t2 + H) >> SHIFT;
+    y[2] = (tmp12 + t1 + H) >> SHIFT;
+    y[5] = (tmp12 - t1 + H) >> SHIFT;
+    y[3] = (tmp13 + t0 + H) >> SHIFT;
+    y[4] = (tmp13 - t0 + H) >> SHIFT;
+}
+
+constexpr int IDCT_BLOCKS = 32;  // blocks per workgroup (8 threads each)
+constexpr int WS_PITCH = 72;
+
+__global__ __launch_bounds__(IDCT_BLOCKS * 8) void jpeg_idct_kernel(const JpegDev* hdr, const int16_t* coef, uint8_t* planes) {
+    __shared__ int16_t cs[IDCT_BLOCKS * 64];
+    __shared__ int ws[IDCT_BLOCKS * WS_PITCH];
+    __shared__ uint16_t qs[3 * 64];
+    const int t = threadIdx.x;
+    const long b0 = long(blockIdx.x) * IDCT_BLOCKS;
+    const int total = hdr->total_blocks;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(coef + b0 * 64);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(cs);
+        const long avail = (long(total) - b0) * 32;  // words
+        for (int i = t; i < IDCT_BLOCKS * 32; i += IDCT_BLOCKS * 8) dst[i] = i < avail ? src[i] : 0u;
+        if (t < 3 * 64) qs[t] = (&hdr->quant[0][0])[t];
+    }
+    __syncthreads();
+    const int bl = t >> 3, i = t & 7;
+    const long b = b0 + bl;
+    const bool live = b < total;
+    const int bi = live ? int(b % hdr->bpm) : 0;
+    const long mcu = live ? b / hdr->bpm : 0;
+    const int comp = hdr->blk_comp[bi];
+    {
+        int x[8], y[8];
+        for (int r = 0; r < 8; ++r) x[r] = int(cs[bl * 64 + r * 8 + i]) * int(qs[comp * 64 + r * 8 + i]);
+        idct8<13 - 2>(x, y);
+        for (int r = 0; r < 8; ++r) ws[bl * WS_PITCH + r * 8 + i] = y[r];
+    }
+    __syncthreads();
+    if (!live) return;
+    int x[8], y[8];
+    for (int c = 0; c < 8; ++c) x[c] = ws[bl * WS_PITCH + i * 8 + c];
+    idct8<13 + 2 + 3>(x, y);
+    uint32_t lo = 0, hi = 0;
+    for (int c = 0; c < 4; ++c) {
+        lo |= uint32_t(min(255, max(0, y[c] + 128))) << (8 * c);
+        hi |= uint32_t(min(255, max(0, y[c + 4] + 128))) << (8 * c);
+    }
+    const int my = int(mcu / hdr->mcus_x), mx = int(mcu % hdr->mcus_x);
+    const int hc = comp == 0 ? hdr->hmax : 1, vc = comp == 0 ? hdr->vmax : 1;
+    const int px = (mx * hc + hdr->blk_bx[bi]) * 8, py = (my * vc + hdr->blk_by[bi]) * 8 + i;
+    uint8_t* dst = planes + hdr->plane_off[comp] + long(py) * hdr->plane_w[comp] + px;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+}
+
+// chroma upsampling (jdsample.c h2v1_fancy_upsample / h2v2_fancy_upsample, or replication for the narrow images libjpeg
+// does not filter) + jdcolor.c ycc_rgb_convert; four pixels per thread
+__global__ __launch_bounds__(256) void jpeg_colour_kernel(const JpegDev* hdr, const uint8_t* planes, uint8_t* rgb) {
+    const int W = hdr->width, H = hdr->height;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x0 >= W || y >= H) return;
+    const uint8_t* Y = planes + hdr->plane_off[0] + long(y) * hdr->plane_w[0];
+    int r[4], g[4], b[4];
+    if (hdr->ncomp == 1) {
+        for (int i = 0; i < 4; ++i) r[i] = g[i] = b[i] = Y[min(x0 + i, hdr->plane_w[0] - 1)];
+    } else {
+        const int pw = hdr->plane_w[1], dw = hdr->real_w[1], dh = hdr->real_h[1];
+        const uint8_t* CB = planes + hdr->plane_off[1];
+        const uint8_t* CR = planes + hdr->plane_off[2];
+        int cb[4], cr[4];
+        if (hdr->hmax == 1) {
+            for (int i = 0; i < 4; ++i) {
+                const int x = min(x0 + i, dw - 1);
+                cb[i] = CB[long(y) * pw + x];
+                cr[i] = CR[long(y) * pw + x];
+            }
+        } else if (!hdr->fancy) {
+            const int cy = hdr->vmax == 2 ? y >> 1 : y;
+            for (int i = 0; i < 4; ++i) {
+                const int x = min((x0 + i) >> 1, dw - 1);
+                cb[i] = CB[long(cy) * pw + x];
+                cr[i] = CR[long(cy) * pw + x];
+            }
+        } else if (hdr->vmax == 1) {
+            const int c0 = x0 >> 1;
+            for (int pl = 0; pl < 2; ++pl) {
+                const uint8_t* P = (pl ? CR : CB) + long(y) * pw;
+                int* o = pl ? cr : cb;
+                const int a = P[max(c0 - 1, 0)], m0 = P[min(c0, dw - 1)], m1 = P[min(c0 + 1, dw - 1)], z = P[min(c0 + 2, dw - 1)];
+                o[0] = (3 * m0 + a + 1) >> 2;
+                o[1] = (3 * m0 + m1 + 2) >> 2;
+                o[2] = (3 * m1 + m0 + 1) >> 2;
+                o[3] = (3 * m1 + z + 2) >> 2;
+            }
+        } else {
+            const int c0 = x0 >> 1, cy = y >> 1;
+            const int oy = (y & 1) ? min(cy + 1, dh - 1) : max(cy - 1, 0);
+            for (int pl = 0; pl < 2; ++pl) {
+                const uint8_t* P0 = (pl ? CR : CB) + long(cy) * pw;
+                const uint8_t* P1 = (pl ? CR : CB) + long(oy) * pw;
+                int* o = pl ? cr : cb;
+                const int xa = max(c0 - 1, 0), xm0 = min(c0, dw - 1), xm1 = min(c0 + 1, dw - 1), xz = min(c0 + 2, dw - 1);
+                const int a = 3 * P0[xa] + P1[xa], m0 = 3 * P0[xm0] + P1[xm0], m1 = 3 * P0[xm1] + P1[xm1], z = 3 * P0[xz] + P1[xz];
+                o[0] = (3 * m0 + a + 8) >> 4;
+                o[1] = (3 * m0 + m1 + 7) >> 4;
+                o[2] = (3 * m1 + m0 + 8) >> 4;
+                o[3] = (3 * m1 + z + 7) >> 4;
+            }
+        }
+        for (int i = 0; i < 4; ++i) {
+            const int yy = Y[min(x0 + i, hdr->plane_w[0] - 1)];
+            const int u = cb[i] - 128, v = cr[i] - 128;
+            r[i] = min(255, max(0, yy + ((91881 * v + 32768) >> 16)));
+            g[i] = min(255, max(0, yy + ((-22554 * u + 32768 - 46802 * v) >> 16)));
+            b[i] = min(255, max(0, yy + ((116130 * u + 32768) >> 16)));
+        }
+    }
+    uint8_t* out = rgb + (long(y) * W + x0) * 3;
+    if ((W & 3) == 0) {
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
+        o32[0] = uint32_t(r[0]) | uint32_t(g[0]) << 8 | uint32_t(b[0]) << 16 | uint32_t(r[1]) << 24;
+        o32[1] = uint32_t(g[1]) | uint32_t(b[1]) << 8 | uint32_t(r[2]) << 16 | uint32_t(g[2]) << 24;
+        o32[2] = uint32_t(b[2]) | uint32_t(r[3]) << 8 | uint32_t(g[3]) << 16 | uint32_t(b[3]) << 24;
+    } else {
+        for (int i = 0; i < 4 && x0 + i < W; ++i) {
+            out[3 * i] = uint8_t(r[i]);
+            out[3 * i + 1] = uint8_t(g[i]);
+            out[3 * i + 2] = uint8_t(b[i]);
+        }
+    }
+}
+
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+// Device work of one decode on `stream`: the staged blob goes up, the kernels run, rgb_dev [H, W, 3] is complete when the
+// stream has passed.  The host waits for the stream twice (the convergence check of the synchronisation rounds, the "every
+// restart interval is complete" check).  0: done; 1: HIP failure (ctx->fail); 2: the stream did not decode (why).
+// Caller holds ctx->upload_mu (the scratch below belongs to the upload path).
+int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned, uint8_t* rgb_dev, hipStream_t stream,
+                  std::string& why, int* rounds_out) {
+    const JpegDev& d = plan.dev;
+    const size_t n_sub = size_t(d.n_sub);
+    size_t plane_bytes = 0;
+    for (int c = 0; c < d.ncomp; ++c) plane_bytes += size_t(d.plane_w[c]) * d.plane_h[c];
+    // scratch layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += up256(bytes);
+        return o;
+    };
+    const size_t o_blob = take(plan.stage_used);
+    const size_t o_in = take(3 * n_sub * 4);
+    const size_t o_out = take(n_sub * 4), o_nblk = take(n_sub * 4), o_dc = take(3 * n_sub * 4), o_base = take(4 * n_sub * 4);
+    const size_t o_flags = take((MAX_ROUNDS + 8) * 4);
+    const size_t o_coef = take(size_t(d.total_blocks) * 128);
+    const size_t o_planes = take(plane_bytes + 16);
+    if (ctx->jpeg_scratch_cap < off) {
+        if (ctx->jpeg_scratch) {
+            MVLM_CHECK_HIP(ctx, hipStreamSynchronize(stream));
+            (void)hipFree(ctx->jpeg_scratch);
+            ctx->jpeg_scratch = nullptr;
+            ctx->jpeg_scratch_cap = 0;
+        }
+        const size_t cap = off + off / 4;
+        MVLM_CHECK_HIP(ctx, hipMalloc(&ctx->jpeg_scratch, cap));
+        ctx->jpeg_scratch_cap = cap;
+    }
+    if (!ctx->jpeg_flags_host) MVLM_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->jpeg_flags_host), (MAX_ROUNDS + 8) * 4, hipHostMallocDefault));
+    auto* base = static_cast<uint8_t*>(ctx->jpeg_scratch);
+    const auto* hdr = reinterpret_cast<const JpegDev*>(base + o_blob);
+    const auto* words = reinterpret_cast<const uint32_t*>(base + o_blob + plan.off_stream);
+    const long total_words = long(plan.stream_bytes / 4);
+    const auto* sub_seg = reinterpret_cast<const int32_t*>(base + o_blob + plan.off_subseg);
+    auto* in3 = reinterpret_cast<uint32_t*>(base + o_in);
+    auto* out_state = reinterpret_cast<uint32_t*>(base + o_out);
+    auto* out_nblk = reinterpret_cast<int32_t*>(base + o_nblk);
+    auto* out_dc = reinterpret_cast<int32_t*>(base + o_dc);
+    auto* prefix = reinterpret_cast<int32_t*>(base + o_base);
+    auto* flags = reinterpret_cast<int32_t*>(base + o_flags);  // [round] "changed", [MAX_ROUNDS] "short"
+    auto* coef = reinterpret_cast<int16_t*>(base + o_coef);
+    uint8_t* planes = base + o_planes;
+
+    MVLM_CHECK_HIP(ctx, hipMemcpyAsync(base + o_blob, stage_pinned, plan.stage_used, hipMemcpyHostToDevice, stream));
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(in3, 0, 3 * n_sub * 4, stream));
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(flags, 0, (MAX_ROUNDS + 8) * 4, stream));
+    MVLM_CHECK_HIP(ctx, hipMemsetAsync(coef, 0, size_t(d.total_blocks) * 128, stream));
+    const unsigned dec_grid = unsigned((n_sub + DEC_WG - 1) / DEC_WG);
+    int final_round = -1;
+    for (int r0 = 0; r0 < MAX_ROUNDS && final_round < 0; r0 += ROUNDS_PER_BATCH) {
+        for (int r = r0; r < r0 + ROUNDS_PER_BATCH; ++r) {
+            const uint32_t* prev = in3 + size_t((r + 2) % 3) * n_sub;
+            const uint32_t* cur = in3 + size_t(r % 3) * n_sub;
+            uint32_t* next = in3 + size_t((r + 1) % 3) * n_sub;
+            hipLaunchKernelGGL(jpeg_sync_kernel, dim3(dec_grid), dim3(DEC_WG), 0, stream, hdr, words, total_words, sub_seg, prev, cur,
+                               next, out_state, out_nblk, out_dc, flags, r);
+        }
+        MVLM_CHECK_HIP(ctx, hipGetLastError());
+        MVLM_CHECK_HIP(ctx, hipMemcpyAsync(ctx->jpeg_flags_host + r0, flags + r0, ROUNDS_PER_BATCH * 4, hipMemcpyDeviceToHost, stream));
+        MVLM_CHECK_HIP(ctx, hipStreamSynchronize(stream));
+        for (int r = r0; r < r0 + ROUNDS_PER_BATCH; ++r)
+            if (ctx->jpeg_flags_host[r] == 0) {
+                final_round = r;
+                break;
+            }
+    }
+    if (rounds_out) *rounds_out = final_round;
+    if (final_round < 0) {
+        why = "the subsequence decoders did not synchronise";
+        return 2;
+    }
+    const uint32_t* in_final = in3 + size_t(final_round % 3) * n_sub;
+    hipLaunchKernelGGL(jpeg_scan_kernel, dim3(1), dim3(1024), 0, stream, hdr, sub_seg, out_nblk, out_dc, prefix, flags + MAX_ROUNDS, plan.n_seg);
+    hipLaunchKernelGGL(jpeg_write_kernel, dim3(dec_grid), dim3(DEC_WG), 0, stream, hdr, words, total_words, sub_seg, in_final, prefix, coef);
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3(unsigned((d.total_blocks + IDCT_BLOCKS - 1) / IDCT_BLOCKS)), dim3(IDCT_BLOCKS * 8), 0, stream,
+                       hdr, coef, planes);
+    hipLaunchKernelGGL(jpeg_colour_kernel, dim3(unsigned((d.width + 1023) / 1024), unsigned(d.height)), dim3(256), 0, stream, hdr, planes, rgb_dev);
+    MVLM_CHECK_HIP(ctx, hipGetLastError());
+    MVLM_CHECK_HIP(ctx, hipMemcpyAsync(ctx->jpeg_flags_host + MAX_ROUNDS, flags + MAX_ROUNDS, 4, hipMemcpyDeviceToHost, stream));
+    MVLM_CHECK_HIP(ctx, hipStreamSynchronize(stream));
+    if (ctx->jpeg_flags_host[MAX_ROUNDS]) {
+        why = "the entropy-coded segment ends before the image does";
+        return 2;
+    }
+    return 0;
+}

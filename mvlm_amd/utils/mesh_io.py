@@ -33,6 +33,9 @@ class Mesh:
     # 4x4 matrix of the config's "pre-align" block this mesh has been through (utils/prealign.py); landmarks found on
     # it go back to the file's own coordinates through the inverse (utils3d.py:505-527)
     to_original: np.ndarray | None = None
+    # The texture as the bytes of its JPEG file, not decoded yet (load_obj / load_mesh with decode="device").  The renderer's
+    # upload hands them to the device decoder (mvlm_mesh_upload_jpeg); ``texture`` decodes them with libjpeg on first use.
+    texture_jpeg: bytes | None = field(default=None, repr=False)
 
     @property
     def n_verts(self) -> int:
@@ -41,6 +44,36 @@ class Mesh:
     @property
     def n_tris(self) -> int:
         return int(self.tris.shape[0])
+
+
+def _lazy_texture(self):
+    if self._texture is None and self.texture_jpeg is not None:
+        self._texture = decode_texture_bytes(self.texture_jpeg)
+        if self._texture is None:
+            self.texture_jpeg = None  # "if we cannot load the texture, we just ignore it" (utils3d.py:35-36)
+    return self._texture
+
+
+def _set_texture(self, value):
+    self._texture = value
+
+
+Mesh.texture = property(_lazy_texture, _set_texture)  # (the dataclass' __init__ assigns through the setter)
+
+
+def decode_texture_bytes(data: bytes):
+    """Image file bytes -> [H,W,3] uint8 with libjpeg (Pillow), None if it does not decode."""
+    try:
+        import io
+
+        from PIL import Image
+
+        with Image.open(io.BytesIO(data)) as im:
+            if im.mode != "RGB":
+                im = im.convert("RGB")
+            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def _parse_obj(text: str):
@@ -144,20 +177,33 @@ def _read_obj_python(path: Path):
     return np.ascontiguousarray(verts), np.asarray(tris, dtype=np.int32).reshape(-1, 3), uvs
 
 
-def load_obj(path: Union[Path, str], load_texture: bool = True, reader: str = "native") -> Mesh:
-    """OBJ + same-stem ``.jpg`` -> Mesh.  The JPEG is decoded on a second thread while the
-    geometry is parsed (both release the GIL)."""
+def load_obj(path: Union[Path, str], load_texture: bool = True, reader: str = "native", decode: str = "device") -> Mesh:
+    """OBJ + same-stem ``.jpg`` -> Mesh.
+
+    ``decode="device"`` (default): the JPEG file is only read; the Mesh carries its bytes (``texture_jpeg``) and the renderer's
+    upload decodes them on the GPU (``mvlm_mesh_upload_jpeg``, byte for byte libjpeg's result).  ``mesh.texture`` still
+    gives the pixels - decoded with libjpeg on first use.  ``decode="host"``: libjpeg on a second thread while the
+    geometry is parsed (both release the GIL), as in rounds 1-4."""
     path = Path(path)
     if not path.is_file():
         raise ValueError(f"File {path} does not exist.")  # utils3d.py:13-14
+    if decode not in ("device", "host"):
+        raise ValueError(f"unknown texture decode mode: {decode}")
     jpg = path.with_suffix(".jpg")
     tex_job = None
+    jpeg_bytes = None
     if load_texture and jpg.exists():
-        import threading
+        if decode == "device":
+            try:
+                jpeg_bytes = jpg.read_bytes()
+            except OSError:
+                jpeg_bytes = None
+        else:
+            import threading
 
-        box: list = [None]
-        tex_job = threading.Thread(target=lambda: box.__setitem__(0, _read_texture(jpg)), daemon=True)
-        tex_job.start()
+            box: list = [None]
+            tex_job = threading.Thread(target=lambda: box.__setitem__(0, _read_texture(jpg)), daemon=True)
+            tex_job.start()
     try:
         if reader == "native":
             verts, tris, uvs = _read_obj_native(path)
@@ -169,7 +215,7 @@ def load_obj(path: Union[Path, str], load_texture: bool = True, reader: str = "n
         if tex_job is not None:
             tex_job.join()
     texture = box[0] if (tex_job is not None and uvs is not None) else None  # utils3d.py:26: only with tcoords
-    return Mesh(verts, tris, uvs, texture, path)
+    return Mesh(verts, tris, uvs, texture, path, texture_jpeg=jpeg_bytes if uvs is not None else None)
 
 
 SURFACE_SUFFIXES = (".obj", ".wrl", ".vtk", ".stl", ".ply")  # Utils3D.multi_read_surface, utils3d.py:389-423
@@ -195,29 +241,39 @@ def find_texture(path: Union[Path, str], texture_file_name=None) -> Path | None:
     return found
 
 
-def load_mesh(path: Union[Path, str], load_texture: bool = True, texture_file_name=None) -> Mesh:
+def load_mesh(path: Union[Path, str], load_texture: bool = True, texture_file_name=None, decode: str = "device") -> Mesh:
     """Any surface format of the reference's legacy reader (``.obj .wrl .vtk .stl .ply``, utils3d.py:389-423)
     with the texture looked up by ``find_texture`` (``.bmp / .png / .jpg``, :425-462) -> Mesh.  ``load_obj`` is
-    the live pipeline's stricter OBJ + same-stem JPEG ingest (utils3d.py:10-36)."""
+    the live pipeline's stricter OBJ + same-stem JPEG ingest (utils3d.py:10-36).  A ``.jpg`` texture is decoded on the
+    device at upload time unless ``decode="host"`` (see ``load_obj``); ``.bmp`` / ``.png`` always on the host."""
     path = Path(path)
     if not path.is_file():
         raise ValueError(f"File {path} does not exist.")
     if path.suffix.lower() not in SURFACE_SUFFIXES:
         raise ValueError(f"Can not read files with extension {path.suffix}")  # utils3d.py:421-422
+    if decode not in ("device", "host"):
+        raise ValueError(f"unknown texture decode mode: {decode}")
     tex_path = find_texture(path, texture_file_name) if load_texture else None
     tex_job, box = None, [None]
+    jpeg_bytes = None
     if tex_path is not None and tex_path.suffix.lower() in (".bmp", ".png", ".jpg") and tex_path.is_file():
-        import threading
+        if decode == "device" and tex_path.suffix.lower() == ".jpg":
+            try:
+                jpeg_bytes = tex_path.read_bytes()
+            except OSError:
+                jpeg_bytes = None
+        else:
+            import threading
 
-        tex_job = threading.Thread(target=lambda: box.__setitem__(0, _read_texture(tex_path)), daemon=True)
-        tex_job.start()
+            tex_job = threading.Thread(target=lambda: box.__setitem__(0, _read_texture(tex_path)), daemon=True)
+            tex_job.start()
     try:
         verts, tris, uvs = _read_obj_native(path, any_format=True)
     finally:
         if tex_job is not None:
             tex_job.join()
     texture = box[0] if uvs is not None else None
-    return Mesh(verts, tris, uvs, texture, path)
+    return Mesh(verts, tris, uvs, texture, path, texture_jpeg=jpeg_bytes if uvs is not None else None)
 
 
 def write_obj(path: Union[Path, str], verts: np.ndarray, tris: np.ndarray, uvs: np.ndarray | None = None,

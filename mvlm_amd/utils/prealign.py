@@ -46,7 +46,9 @@ def apply_prealign(mesh: Mesh, cfg: dict) -> tuple[Mesh, np.ndarray]:
     The copy remembers the matrix (``Mesh.to_original``) so whoever ends up with the landmarks can map them back."""
     m = prealign_matrix(mesh.verts, cfg)
     v = mesh.verts.astype(np.float64) @ m[:3, :3].T + m[:3, 3]
-    return Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, mesh.texture, mesh.path, to_original=m), m
+    # (a texture that is still the JPEG file's bytes stays that way: the upload decodes it on the device)
+    return Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, getattr(mesh, "_texture", None), mesh.path, to_original=m,
+                texture_jpeg=mesh.texture_jpeg), m
 
 
 def aligned(mesh: Mesh, cfg: dict | None) -> Mesh:

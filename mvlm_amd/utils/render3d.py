@@ -66,12 +66,25 @@ def upload_mesh(ctx: "_lib.Context", mesh: Mesh) -> C.c_void_p:
     verts = np.ascontiguousarray(mesh.verts, dtype=np.float32)
     tris = np.ascontiguousarray(mesh.tris, dtype=np.int32)
     uvs = None if mesh.uvs is None else np.ascontiguousarray(mesh.uvs, dtype=np.float32)
-    tex = None if mesh.texture is None else np.ascontiguousarray(mesh.texture, dtype=np.uint8)
     handle = C.c_void_p()
-    ctx.check(ctx.lib.mvlm_mesh_upload(
-        ctx.handle, _lib.as_ptr(verts, C.c_float), None if uvs is None else _lib.as_ptr(uvs, C.c_float), mesh.n_verts,
-        _lib.as_ptr(tris, C.c_int32), mesh.n_tris, None if tex is None else _lib.as_ptr(tex, C.c_uint8),
-        0 if tex is None else tex.shape[0], 0 if tex is None else tex.shape[1], C.byref(handle)), ValueError)
+    uploaded = False
+    if uvs is not None and mesh.texture_jpeg is not None and getattr(mesh, "_texture", None) is None:
+        # the texture is still the JPEG file's bytes: entropy decoding, inverse DCT, upsampling and colour conversion on
+        # the device (csrc/jpeg.hip).  2 = a kind of JPEG that decoder does not take: libjpeg on the host below
+        raw = np.frombuffer(mesh.texture_jpeg, dtype=np.uint8)
+        rc = ctx.lib.mvlm_mesh_upload_jpeg(
+            ctx.handle, _lib.as_ptr(verts, C.c_float), _lib.as_ptr(uvs, C.c_float), mesh.n_verts, _lib.as_ptr(tris, C.c_int32),
+            mesh.n_tris, _lib.as_ptr(raw, C.c_uint8), raw.size, C.byref(handle))
+        if rc == 0:
+            uploaded = True
+        elif rc != 2:
+            ctx.check(rc, ValueError)
+    if not uploaded:
+        tex = None if mesh.texture is None else np.ascontiguousarray(mesh.texture, dtype=np.uint8)
+        ctx.check(ctx.lib.mvlm_mesh_upload(
+            ctx.handle, _lib.as_ptr(verts, C.c_float), None if uvs is None else _lib.as_ptr(uvs, C.c_float), mesh.n_verts,
+            _lib.as_ptr(tris, C.c_int32), mesh.n_tris, None if tex is None else _lib.as_ptr(tex, C.c_uint8),
+            0 if tex is None else tex.shape[0], 0 if tex is None else tex.shape[1], C.byref(handle)), ValueError)
 
     class _Owner:  # frees the device copy with the Mesh
         def __init__(self, ctx, h):
