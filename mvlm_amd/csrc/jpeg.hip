@@ -27,9 +27,10 @@ namespace {
 constexpr int SUB_WORDS = 32;               // 32-bit words per subsequence
 constexpr int SUB_BITS = SUB_WORDS * 32;    // 1024
 constexpr int SUB_BYTES = SUB_WORDS * 4;    // 128
-constexpr int DEC_WG = 64;                  // subsequences (= threads) per workgroup of the decode kernels
+constexpr int DEC_WG = 256;                 // subsequences (= threads) per workgroup of the decode kernels
 constexpr int DEC_PITCH = DEC_WG + 1;       // LDS row pitch of the transposed stream words (odd: no bank pattern)
-constexpr int LUT_BITS = 9;
+constexpr int LUT_BITS = 10;                // codes up to this length decode with one table read
+constexpr int N_LONG = 16 - LUT_BITS + 1;   // lengths LUT_BITS .. 16: the limits the longer codes are found with
 constexpr int N_SLOTS = 6;                  // Huffman tables on the device: DC of component c in slot c, AC in slot 3 + c
 constexpr int ROUNDS_PER_BATCH = 24;
 constexpr int MAX_ROUNDS = 480;
@@ -45,13 +46,18 @@ struct JpegDev {
     int n_sub, total_blocks, seg_blocks, fancy;
     int blk_comp[8], blk_bx[8], blk_by[8];
     int plane_w[3], plane_h[3], real_w[3], real_h[3], plane_off[3];
+    uint32_t comp_packed;                  // component of block b of the MCU in bits [2b, 2b + 1]
     uint16_t quant[3][64];                 // natural order
-    uint16_t lut[N_SLOTS][1 << LUT_BITS];  // length << 8 | symbol for codes of at most LUT_BITS bits, else 0
-    int32_t maxcode[N_SLOTS][17];          // [length]: the largest code of that length, -1 if none
-    int32_t valoff[N_SLOTS][17];           // [length]: index of its first symbol minus its smallest code
+    alignas(16) uint16_t lut[N_SLOTS][1 << LUT_BITS];  // length << 8 | symbol for codes of at most LUT_BITS bits, else 0
+    // Canonical codes, left-aligned to 16 bits: limit[i] = one past the last code of length LUT_BITS + i (= the first code
+    // of the next length).  A 16-bit window w that misses the table has length LUT_BITS + #{i : w >= limit[i]}, and its
+    // symbol is vals[valptr[i] + ((w - limit[i - 1]) >> (16 - length))] with i = length - LUT_BITS.
+    uint32_t limit[N_SLOTS][8];
+    uint8_t valptr[N_SLOTS][8];
     uint8_t vals[N_SLOTS][256];
     uint8_t nat[64];
 };
+static_assert(N_LONG <= 8, "limit table");
 
 struct HuffHost {
     bool have = false;
@@ -78,21 +84,32 @@ inline int rd16(const uint8_t* p) { return (int(p[0]) << 8) | p[1]; }
 void build_slot(JpegDev& d, int slot, const HuffHost& h) {
     std::memset(d.lut[slot], 0, sizeof(d.lut[slot]));
     std::memcpy(d.vals[slot], h.vals, 256);
-    int code = 0, k = 0;
+    for (int i = 0; i < 8; ++i) {
+        d.limit[slot][i] = 0x10000u;
+        d.valptr[slot][i] = 0;
+    }
+    uint32_t code = 0;
+    int k = 0;
     for (int len = 1; len <= 16; ++len) {
         const int n = h.counts[len - 1];
-        d.valoff[slot][len] = k - code;
+        if (len >= LUT_BITS) d.valptr[slot][len - LUT_BITS] = uint8_t(k);
         for (int i = 0; i < n; ++i, ++code, ++k) {
             if (len <= LUT_BITS) {
-                const int first = code << (LUT_BITS - len);
-                for (int f = 0; f < (1 << (LUT_BITS - len)); ++f) d.lut[slot][first + f] = uint16_t((len << 8) | h.vals[k]);
+                const uint32_t first = code << (LUT_BITS - len);
+                for (uint32_t f = 0; f < (1u << (LUT_BITS - len)); ++f) d.lut[slot][first + f] = uint16_t((len << 8) | h.vals[k]);
             }
         }
-        d.maxcode[slot][len] = n ? code - 1 : -1;
+        if (len >= LUT_BITS) d.limit[slot][len - LUT_BITS] = code << (16 - len);
         code <<= 1;
     }
-    d.maxcode[slot][0] = -1;
-    d.valoff[slot][0] = 0;
+}
+
+void no_codes_slot(JpegDev& d, int slot) {  // a slot no component uses: every window is invalid
+    std::memset(d.lut[slot], 0, sizeof(d.lut[slot]));
+    for (int i = 0; i < 8; ++i) {
+        d.limit[slot][i] = 0;
+        d.valptr[slot][i] = 0;
+    }
 }
 
 }  // namespace
@@ -284,10 +301,12 @@ int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::
         d.plane_off[c] = off;
         off += d.plane_w[c] * d.plane_h[c];
     }
-    for (int c = d.ncomp; c < 3; ++c) {  // unused slots: every code invalid
-        for (int s : {c, 3 + c})
-            for (int l = 0; l <= 16; ++l) d.maxcode[s][l] = -1;
+    for (int c = d.ncomp; c < 3; ++c) {
+        no_codes_slot(d, c);
+        no_codes_slot(d, 3 + c);
     }
+    d.comp_packed = 0;
+    for (int b = 0; b < d.bpm; ++b) d.comp_packed |= uint32_t(d.blk_comp[b]) << (2 * b);
     std::memcpy(d.nat, kNatural, 64);
     plan.n_mcus = size_t(d.mcus_x) * d.mcus_y;
     if (plan.n_mcus * d.bpm > (size_t(1) << 26)) {
@@ -385,44 +404,73 @@ namespace {
 
 struct DecLds {
     uint32_t words[SUB_WORDS * DEC_PITCH];
-    uint16_t lut[N_SLOTS][1 << LUT_BITS];
-    int32_t maxcode[N_SLOTS][17];
-    int32_t valoff[N_SLOTS][17];
+    alignas(16) uint16_t lut[N_SLOTS][1 << LUT_BITS];
+    uint32_t limit[N_SLOTS][8];
+    uint8_t valptr[N_SLOTS][8];
     uint8_t vals[N_SLOTS][256];
     uint8_t nat[64];
-    int blk_comp[8];
 };
 
+// 16-byte loads, all of a thread's loads in flight before the first store (a loop of dependent 4-byte load -> store pairs
+// on one wave cost 70 us per launch - more than the decoding itself)
 __device__ inline void dec_stage(DecLds& L, const JpegDev* hdr, const uint32_t* stream, long total_words, int sub0) {
     const int t = threadIdx.x;
     // this workgroup's DEC_WG subsequences and the one behind them, word j of subsequence c at [j][c]
-    const long w0 = long(sub0) * SUB_WORDS;
-    for (int i = t; i < SUB_WORDS * DEC_PITCH; i += DEC_WG) {
-        const long g = w0 + i;
-        const uint32_t v = g < total_words ? stream[g] : 0xFFFFFFFFu;
-        L.words[(i % SUB_WORDS) * DEC_PITCH + i / SUB_WORDS] = __builtin_bswap32(v);
+    const long q0 = long(sub0) * (SUB_WORDS / 4);
+    const long total_quads = total_words / 4;
+    const uint4* src4 = reinterpret_cast<const uint4*>(stream);
+    constexpr int QUADS = SUB_WORDS / 4 * DEC_PITCH;
+    constexpr int Q_ITERS = (QUADS + DEC_WG - 1) / DEC_WG;
+    uint4 v[Q_ITERS];
+#pragma unroll
+    for (int it = 0; it < Q_ITERS; ++it) {
+        const int i = it * DEC_WG + t;
+        const long g = q0 + i;
+        v[it] = (i < QUADS && g < total_quads) ? src4[g] : make_uint4(~0u, ~0u, ~0u, ~0u);
     }
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(hdr->lut);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(L.lut);
-    constexpr int TAB_WORDS = (sizeof(L.lut) + sizeof(L.maxcode) + sizeof(L.valoff) + sizeof(L.vals) + sizeof(L.nat)) / 4;
+    constexpr int TAB_QUADS = (sizeof(L.lut) + sizeof(L.limit) + sizeof(L.valptr) + sizeof(L.vals) + sizeof(L.nat)) / 16;
+    static_assert((sizeof(L.lut) + sizeof(L.limit) + sizeof(L.valptr) + sizeof(L.vals) + sizeof(L.nat)) % 16 == 0, "table size");
     static_assert(offsetof(DecLds, nat) - offsetof(DecLds, lut) == offsetof(JpegDev, nat) - offsetof(JpegDev, lut), "table layout");
-    for (int i = t; i < TAB_WORDS; i += DEC_WG) dst[i] = src[i];
-    if (t < 8) L.blk_comp[t] = hdr->blk_comp[t];
+    static_assert(offsetof(JpegDev, lut) % 16 == 0 && offsetof(DecLds, lut) % 16 == 0 && offsetof(DecLds, limit) % 16 == 0, "table alignment");
+    constexpr int T_ITERS = (TAB_QUADS + DEC_WG - 1) / DEC_WG;
+    const uint4* tsrc = reinterpret_cast<const uint4*>(hdr->lut);
+    uint4* tdst = reinterpret_cast<uint4*>(L.lut);
+    uint4 tv[T_ITERS];
+#pragma unroll
+    for (int it = 0; it < T_ITERS; ++it) {
+        const int i = it * DEC_WG + t;
+        tv[it] = i < TAB_QUADS ? tsrc[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < Q_ITERS; ++it) {
+        const int i = it * DEC_WG + t;
+        if (i < QUADS) {
+            const int c = i / (SUB_WORDS / 4), j = (i % (SUB_WORDS / 4)) * 4;
+            L.words[(j + 0) * DEC_PITCH + c] = __builtin_bswap32(v[it].x);
+            L.words[(j + 1) * DEC_PITCH + c] = __builtin_bswap32(v[it].y);
+            L.words[(j + 2) * DEC_PITCH + c] = __builtin_bswap32(v[it].z);
+            L.words[(j + 3) * DEC_PITCH + c] = __builtin_bswap32(v[it].w);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < T_ITERS; ++it) {
+        const int i = it * DEC_WG + t;
+        if (i < TAB_QUADS) tdst[i] = tv[it];
+    }
     __syncthreads();
 }
 
 // One subsequence from the state `in` (bit offset | block in MCU << 8 | zigzag index << 16) to the first symbol that
 // starts behind its last bit.  WRITE: the coefficients go to coef (absolute block `ablk`, at most up to `blk_limit`),
-// dc[] are the running predictors; otherwise dc[] collects the sums of the DC differences and n_blk the blocks completed.
+// dc0..2 are the running predictors; otherwise they collect the sums of the DC differences, n_blk the blocks completed.
 template <bool WRITE>
-__device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, int bpm, int& n_blk, int dc[3], int16_t* coef,
-                                           long ablk, long blk_limit) {
+__device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, int bpm, uint32_t comp_packed, int& n_blk, int& dc0,
+                                           int& dc1, int& dc2, int16_t* coef, long ablk, long blk_limit) {
     int pos = int(in & 0xFF), blk = int((in >> 8) & 0xFF), k = int((in >> 16) & 0xFF);
     auto word = [&](int j) { return L.words[(j & (SUB_WORDS - 1)) * DEC_PITCH + t + (j >> 5)]; };
     int w0 = pos >> 5;
     uint32_t hi = word(w0), lo = word(w0 + 1);
     n_blk = 0;
-    bool dead = false;
     if (WRITE && ablk >= blk_limit) return STATE_DEAD;
     while (pos < SUB_BITS) {
         const int w = pos >> 5;
@@ -432,41 +480,50 @@ __device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, 
             w0 = w;
         }
         const uint32_t peek = uint32_t((((uint64_t(hi) << 32) | lo) << (pos & 31)) >> 32);
-        const int comp = L.blk_comp[blk];
-        const int slot = k == 0 ? comp : 3 + comp;
+        const int comp = int((comp_packed >> (2 * blk)) & 3u);
+        const bool dc_mode = k == 0;
+        const int slot = dc_mode ? comp : 3 + comp;
         const uint32_t e = L.lut[slot][peek >> (32 - LUT_BITS)];
         int len = int(e >> 8), sym = int(e & 255);
         if (len == 0) {
-            for (len = LUT_BITS + 1; len <= 16; ++len) {
-                const int code = int(peek >> (32 - len));
-                if (code <= L.maxcode[slot][len]) {
-                    sym = L.vals[slot][(code + L.valoff[slot][len]) & 255];
-                    break;
+            // a code longer than the table's index: its length from the left-aligned limits, its symbol from the offset to
+            // the first code of that length (three wide reads and one byte instead of a loop over the lengths)
+            const uint4 la = *reinterpret_cast<const uint4*>(&L.limit[slot][0]);
+            const uint4 lb = *reinterpret_cast<const uint4*>(&L.limit[slot][4]);
+            const uint2 vp = *reinterpret_cast<const uint2*>(&L.valptr[slot][0]);
+            const uint32_t lim[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+            const uint32_t w16 = peek >> 16;
+            int i = 0;
+            uint32_t first = 0;
+#pragma unroll
+            for (int j = 0; j < N_LONG; ++j)
+                if (w16 >= lim[j]) {
+                    i = j + 1;
+                    first = lim[j];
                 }
-            }
-            if (len > 16) {
-                dead = true;
-                break;
-            }
+            if (i >= N_LONG) return STATE_DEAD;  // no code starts with these bits
+            len = LUT_BITS + i;
+            const uint32_t ptr = ((i < 4 ? vp.x : vp.y) >> (8 * (i & 3))) & 255u;
+            sym = L.vals[slot][(ptr + ((w16 - first) >> (16 - len))) & 255u];
         }
-        const int s = sym & 15;
+        const int s = sym & 15, r = sym >> 4;
         int val = 0;
         if (s) {
             const int bits = int((peek << len) >> (32 - s));
             val = bits < (1 << (s - 1)) ? bits - (1 << s) + 1 : bits;
         }
         pos += len + s;
-        if (k == 0) {
-            dc[comp] += val;
-            if (WRITE) coef[ablk * 64] = int16_t(dc[comp]);
-            k = 1;
-        } else if (s == 0) {
-            k = (sym >> 4) == 15 ? k + 16 : 64;
-        } else {
-            k += sym >> 4;
-            if (WRITE && k < 64) coef[ablk * 64 + L.nat[k]] = int16_t(val);
-            ++k;
+        // DC: the difference, position 0.  AC: run r then a coefficient, or (s == 0) sixteen zeros / the end of the block.
+        const int kpos = dc_mode ? 0 : k + r;
+        const bool eob = !dc_mode && s == 0 && r != 15;
+        const bool coefficient = dc_mode || s != 0;
+        if (dc_mode) {
+            if (comp == 0) val = (dc0 += val);
+            else if (comp == 1) val = (dc1 += val);
+            else val = (dc2 += val);
         }
+        if (WRITE && coefficient && kpos < 64) coef[ablk * 64 + L.nat[kpos]] = int16_t(val);
+        k = eob ? 64 : kpos + 1;
         if (k >= 64) {
             k = 0;
             blk = blk + 1 == bpm ? 0 : blk + 1;
@@ -474,7 +531,6 @@ __device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, 
             if (WRITE && ++ablk >= blk_limit) return STATE_DEAD;
         }
     }
-    if (dead) return STATE_DEAD;
     return uint32_t(pos - SUB_BITS) | (uint32_t(blk) << 8) | (uint32_t(k) << 16);
 }
 
@@ -494,13 +550,13 @@ __global__ __launch_bounds__(DEC_WG) void jpeg_sync_kernel(const JpegDev* hdr, c
     if (__syncthreads_or(need)) {
         dec_stage(L, hdr, stream, total_words, sub0);
         if (need) {
-            int n_blk, dc[3] = {0, 0, 0};
-            const uint32_t o = dec_subsequence<false>(L, t, in, hdr->bpm, n_blk, dc, nullptr, 0, 0);
+            int n_blk, dc0 = 0, dc1 = 0, dc2 = 0;
+            const uint32_t o = dec_subsequence<false>(L, t, in, hdr->bpm, hdr->comp_packed, n_blk, dc0, dc1, dc2, nullptr, 0, 0);
             out_state[s] = o;
             out_nblk[s] = n_blk;
-            out_dc[3 * s] = dc[0];
-            out_dc[3 * s + 1] = dc[1];
-            out_dc[3 * s + 2] = dc[2];
+            out_dc[3 * s] = dc0;
+            out_dc[3 * s + 1] = dc1;
+            out_dc[3 * s + 2] = dc2;
         }
     }
     if (!mine) return;
@@ -582,8 +638,8 @@ __global__ __launch_bounds__(DEC_WG) void jpeg_write_kernel(const JpegDev* hdr, 
     if (s >= hdr->n_sub) return;
     const long seg0 = long(sub_seg[s]) * hdr->seg_blocks;
     const long limit = min(seg0 + hdr->seg_blocks, long(hdr->total_blocks));
-    int n_blk, dc[3] = {base[4 * s + 1], base[4 * s + 2], base[4 * s + 3]};
-    (void)dec_subsequence<true>(L, t, in_state[s], hdr->bpm, n_blk, dc, coef, seg0 + base[4 * s], limit);
+    int n_blk, dc0 = base[4 * s + 1], dc1 = base[4 * s + 2], dc2 = base[4 * s + 3];
+    (void)dec_subsequence<true>(L, t, in_state[s], hdr->bpm, hdr->comp_packed, n_blk, dc0, dc1, dc2, coef, seg0 + base[4 * s], limit);
 }
 
 // jidctint.c jpeg_idct_islow in 32-bit integers: one pass over eight values, DESCALE by SHIFT

@@ -21,14 +21,15 @@ for _ in range(3):
     pipe.predict_one_file(obj)
 ctx = pipe.renderer_3d.ctx
 def T(): torch.cuda.synchronize(); return time.perf_counter()
-for it in range(4):
-    t0 = T(); mesh = load_obj(obj); t1 = T()
+for it in range(8):
+    mode = "device" if it < 4 else "host"  # where the JPEG texture is decoded
+    t0 = T(); mesh = load_obj(obj, decode=mode); t1 = T()
     upload_mesh(ctx, mesh); t2 = time.perf_counter(); torch.cuda.synchronize(); t3 = time.perf_counter()
     poses = pipe.renderer_3d.generate_3d_transformations()
     t4 = T(); lm, _ = pipe.predict_mesh_device(mesh, poses); t5 = T()
     pipe._after_prediction(obj, lm); t6 = T()
     del mesh; t7 = T()
-    print(f"load {1e3*(t1-t0):.1f}  upload call {1e3*(t2-t1):.1f} (+{1e3*(t3-t2):.1f} until done)  predict_mesh_device {1e3*(t5-t4):.1f}  after {1e3*(t6-t5):.2f}  del {1e3*(t7-t6):.2f}")
+    print(f"[jpeg on the {mode}] load {1e3*(t1-t0):.1f}  upload call {1e3*(t2-t1):.1f} (+{1e3*(t3-t2):.1f} until done)  predict_mesh_device {1e3*(t5-t4):.1f}  after {1e3*(t6-t5):.2f}  del {1e3*(t7-t6):.2f}")
 t0 = T()
 for _ in range(5): pipe.predict_one_file(obj)
 print("predict_one_file avg", 1e3*(T()-t0)/5, pipe.timings)
@@ -46,4 +47,10 @@ for n in ("1", "2", "4", "8"):
     print(f"native OBJ reader, {n} thread(s): {best(lambda: mesh_io._read_obj_native(obj)):.2f} ms")
 del os.environ["MVLM_OBJ_THREADS"]
 print(f"JPEG decode (2048x2048): {best(lambda: mesh_io._read_texture(obj.with_suffix('.jpg'))):.2f} ms")
-print(f"load_obj (both, JPEG on a second thread): {best(lambda: load_obj(obj)):.2f} ms")
+print(f"load_obj (both, JPEG on a second thread): {best(lambda: load_obj(obj, decode='host')):.2f} ms")
+print(f"load_obj (JPEG bytes only, decoded by the upload): {best(lambda: load_obj(obj)):.2f} ms")
+def load_and_upload(mode):
+    m = load_obj(obj, decode=mode); upload_mesh(ctx, m); torch.cuda.synchronize()
+print(f"load_obj + upload until done, JPEG on the host: {best(lambda: load_and_upload('host')):.2f} ms")
+print(f"load_obj + upload until done, JPEG on the device: {best(lambda: load_and_upload('device')):.2f} ms")
+print("texture file:", obj.with_suffix('.jpg').stat().st_size, "bytes")
