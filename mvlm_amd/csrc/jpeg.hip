@@ -29,11 +29,11 @@ constexpr int SUB_BITS = SUB_WORDS * 32;    // 1024
 constexpr int SUB_BYTES = SUB_WORDS * 4;    // 128
 constexpr int DEC_WG = 256;                 // subsequences (= threads) per workgroup of the decode kernels
 constexpr int DEC_PITCH = DEC_WG + 1;       // LDS row pitch of the transposed stream words (odd: no bank pattern)
-constexpr int LUT_BITS = 10;                // codes up to this length decode with one table read
+constexpr int LUT_BITS = 12;                // codes up to this length decode with one table read
 constexpr int N_LONG = 16 - LUT_BITS + 1;   // lengths LUT_BITS .. 16: the limits the longer codes are found with
 constexpr int N_SLOTS = 6;                  // Huffman tables on the device: DC of component c in slot c, AC in slot 3 + c
-constexpr int ROUNDS_PER_BATCH = 24;
-constexpr int MAX_ROUNDS = 480;
+constexpr int FIRST_BATCH = 12, ROUNDS_PER_BATCH = 24;
+constexpr int MAX_ROUNDS = FIRST_BATCH + 20 * ROUNDS_PER_BATCH;
 constexpr uint32_t STATE_DEAD = 0x80000000u;
 
 const uint8_t kNatural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -309,7 +309,7 @@ int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::
     for (int b = 0; b < d.bpm; ++b) d.comp_packed |= uint32_t(d.blk_comp[b]) << (2 * b);
     std::memcpy(d.nat, kNatural, 64);
     plan.n_mcus = size_t(d.mcus_x) * d.mcus_y;
-    if (plan.n_mcus * d.bpm > (size_t(1) << 26)) {
+    if (plan.n_mcus * d.bpm > (size_t(1) << 25)) {
         why = "image too large";
         return 2;
     }
@@ -469,25 +469,28 @@ __device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, 
     int pos = int(in & 0xFF), blk = int((in >> 8) & 0xFF), k = int((in >> 16) & 0xFF);
     auto word = [&](int j) { return L.words[(j & (SUB_WORDS - 1)) * DEC_PITCH + t + (j >> 5)]; };
     int w0 = pos >> 5;
-    uint32_t hi = word(w0), lo = word(w0 + 1);
+    uint32_t hi = word(w0), lo = word(w0 + 1), nx = word(w0 + 2);  // nx: read one word ahead, off the critical path
     n_blk = 0;
     if (WRITE && ablk >= blk_limit) return STATE_DEAD;
+    // The loop is one dependent chain per lane (window -> table entry -> lengths -> next window) and the kernel lasts as
+    // long as its slowest lane, so the body is written with selects instead of branches wherever both sides are cheap.
     while (pos < SUB_BITS) {
         const int w = pos >> 5;
-        if (w != w0) {
-            hi = lo;
-            lo = word(w + 1);
-            w0 = w;
-        }
-        const uint32_t peek = uint32_t((((uint64_t(hi) << 32) | lo) << (pos & 31)) >> 32);
+        const bool adv = w != w0;  // (a symbol is at most 27 bits: the window moves by at most one word)
+        hi = adv ? lo : hi;
+        lo = adv ? nx : lo;
+        nx = word(w + 2);
+        w0 = w;
+        const int sh = pos & 31;
+        const uint32_t peek = sh ? __builtin_amdgcn_alignbit(hi, lo, 32 - sh) : hi;  // the 32 bits at pos
         const int comp = int((comp_packed >> (2 * blk)) & 3u);
         const bool dc_mode = k == 0;
         const int slot = dc_mode ? comp : 3 + comp;
         const uint32_t e = L.lut[slot][peek >> (32 - LUT_BITS)];
         int len = int(e >> 8), sym = int(e & 255);
         if (len == 0) {
-            // a code longer than the table's index: its length from the left-aligned limits, its symbol from the offset to
-            // the first code of that length (three wide reads and one byte instead of a loop over the lengths)
+            // A code longer than the table's index: its length from the left-aligned limits, its symbol from the offset
+            // to the first code of that length.
             const uint4 la = *reinterpret_cast<const uint4*>(&L.limit[slot][0]);
             const uint4 lb = *reinterpret_cast<const uint4*>(&L.limit[slot][4]);
             const uint2 vp = *reinterpret_cast<const uint2*>(&L.valptr[slot][0]);
@@ -507,28 +510,30 @@ __device__ inline uint32_t dec_subsequence(const DecLds& L, int t, uint32_t in, 
             sym = L.vals[slot][(ptr + ((w16 - first) >> (16 - len))) & 255u];
         }
         const int s = sym & 15, r = sym >> 4;
-        int val = 0;
-        if (s) {
-            const int bits = int((peek << len) >> (32 - s));
-            val = bits < (1 << (s - 1)) ? bits - (1 << s) + 1 : bits;
-        }
+        // the s bits behind the code, sign-extended by T.81 F.2.2.1 (s == 0: no bits, value 0)
+        const uint32_t bits = uint32_t(uint64_t(peek << len) >> (32 - s));
+        int val = int(bits) - (bits < ((1u << s) >> 1) ? (1 << s) - 1 : 0);
         pos += len + s;
         // DC: the difference, position 0.  AC: run r then a coefficient, or (s == 0) sixteen zeros / the end of the block.
         const int kpos = dc_mode ? 0 : k + r;
         const bool eob = !dc_mode && s == 0 && r != 15;
         const bool coefficient = dc_mode || s != 0;
-        if (dc_mode) {
-            if (comp == 0) val = (dc0 += val);
-            else if (comp == 1) val = (dc1 += val);
-            else val = (dc2 += val);
-        }
-        if (WRITE && coefficient && kpos < 64) coef[ablk * 64 + L.nat[kpos]] = int16_t(val);
+        // (selects, not an indexed array: "the predictor of component comp" becomes scratch memory otherwise - a scratch
+        // round trip per block)
+        const int dv = dc_mode ? val : 0;
+        dc0 += comp == 0 ? dv : 0;
+        dc1 += comp == 1 ? dv : 0;
+        dc2 += comp == 2 ? dv : 0;
+        val = dc_mode ? (comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2)) : val;
+        if (WRITE && coefficient && kpos < 64) coef[uint32_t(ablk) * 64u + uint32_t(kpos)] = int16_t(val);  // zigzag order
         k = eob ? 64 : kpos + 1;
-        if (k >= 64) {
-            k = 0;
-            blk = blk + 1 == bpm ? 0 : blk + 1;
-            ++n_blk;
-            if (WRITE && ++ablk >= blk_limit) return STATE_DEAD;
+        const bool done = k >= 64;
+        k = done ? 0 : k;
+        blk = done ? (blk + 1 == bpm ? 0 : blk + 1) : blk;
+        n_blk += done ? 1 : 0;
+        if (WRITE) {
+            ablk += done ? 1 : 0;
+            if (ablk >= blk_limit) return STATE_DEAD;
         }
     }
     return uint32_t(pos - SUB_BITS) | (uint32_t(blk) << 8) | (uint32_t(k) << 16);
@@ -571,31 +576,17 @@ __global__ __launch_bounds__(DEC_WG) void jpeg_sync_kernel(const JpegDev* hdr, c
     }
 }
 
-// segmented exclusive prefix sums over the subsequences of every restart interval: blocks completed and DC-difference
-// sums before each subsequence; one workgroup.  short_flag: a restart interval that holds fewer blocks than it must.
-__global__ __launch_bounds__(1024) void jpeg_scan_kernel(const JpegDev* hdr, const int32_t* sub_seg, const int32_t* out_nblk,
-                                                        const int32_t* out_dc, int32_t* base, int32_t* short_flag, int n_seg) {
-    __shared__ int f[1024];
-    __shared__ int v[1024][4];
-    const int n_sub = hdr->n_sub, t = threadIdx.x;
-    const int per = (n_sub + 1023) / 1024;
-    const int s0 = t * per, s1 = min(n_sub, s0 + per);
-    int acc[4] = {0, 0, 0, 0};
-    int flag = 0;
-    for (int s = s0; s < s1; ++s) {
-        if (s == 0 || sub_seg[s] != sub_seg[s - 1]) {
-            flag = 1;
-            acc[0] = acc[1] = acc[2] = acc[3] = 0;
-        }
-        acc[0] += out_nblk[s];
-        acc[1] += out_dc[3 * s];
-        acc[2] += out_dc[3 * s + 1];
-        acc[3] += out_dc[3 * s + 2];
-    }
-    f[t] = flag;
-    for (int i = 0; i < 4; ++i) v[t][i] = acc[i];
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {  // inclusive segmented scan: (f1, v1) + (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2)
+// Segmented exclusive prefix sums over the subsequences of every restart interval - blocks completed and DC-difference
+// sums before each subsequence - in two levels: jpeg_scan_kernel scans SCAN_WG subsequences per workgroup (exclusive
+// values that are final wherever a restart interval began inside the workgroup, "open" = 1 where the workgroup's carry-in
+// still has to be added), jpeg_scan_carry_kernel scans the workgroups' totals.
+constexpr int SCAN_WG = 256;
+constexpr int SCAN_MAX_GROUPS = 1024;
+
+// (f, v) <- (f_left, v_left) (+) (f, v) = (f_left | f, f ? v : v_left + v): inclusive Hillis-Steele scan in LDS
+template <int N>
+__device__ inline void segmented_scan(int (&f)[N], int (&v)[N][4], int t) {
+    for (int d = 1; d < N; d <<= 1) {
         int pf = 0, pv[4] = {0, 0, 0, 0};
         const bool has = t >= d;
         if (has) {
@@ -610,36 +601,65 @@ __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const JpegDev* hdr, con
         }
         __syncthreads();
     }
-    int run[4] = {0, 0, 0, 0};
-    if (t > 0)
-        for (int i = 0; i < 4; ++i) run[i] = v[t - 1][i];
-    for (int s = s0; s < s1; ++s) {
-        const int g = sub_seg[s];
-        if (s == 0 || g != sub_seg[s - 1]) run[0] = run[1] = run[2] = run[3] = 0;
-        for (int i = 0; i < 4; ++i) base[4 * s + i] = run[i];
-        run[0] += out_nblk[s];
-        run[1] += out_dc[3 * s];
-        run[2] += out_dc[3 * s + 1];
-        run[3] += out_dc[3 * s + 2];
-        if (s + 1 == n_sub || sub_seg[s + 1] != g) {
-            const long want = min(long(hdr->seg_blocks), long(hdr->total_blocks) - long(g) * hdr->seg_blocks);
-            if (run[0] < want) atomicOr(short_flag, 1);
-        }
+}
+
+__global__ __launch_bounds__(SCAN_WG) void jpeg_scan_kernel(const JpegDev* hdr, const int32_t* sub_seg, const int32_t* out_nblk,
+                                                           const int32_t* out_dc, int32_t* excl, int32_t* open, int32_t* group_total,
+                                                           int32_t* group_flag) {
+    __shared__ int f[SCAN_WG];
+    __shared__ int v[SCAN_WG][4];
+    const int n_sub = hdr->n_sub, t = threadIdx.x, s = blockIdx.x * SCAN_WG + t;
+    const bool live = s < n_sub;
+    const int first = live && (s == 0 || sub_seg[s] != sub_seg[s - 1]) ? 1 : 0;
+    const int own[4] = {live ? out_nblk[s] : 0, live ? out_dc[3 * s] : 0, live ? out_dc[3 * s + 1] : 0, live ? out_dc[3 * s + 2] : 0};
+    f[t] = first;
+    for (int i = 0; i < 4; ++i) v[t][i] = own[i];
+    __syncthreads();
+    segmented_scan<SCAN_WG>(f, v, t);
+    if (live) {
+        for (int i = 0; i < 4; ++i) excl[4 * s + i] = first ? 0 : v[t][i] - own[i];
+        open[s] = f[t] ? 0 : 1;
+    }
+    if (t == SCAN_WG - 1) {
+        for (int i = 0; i < 4; ++i) group_total[4 * blockIdx.x + i] = v[t][i];
+        group_flag[blockIdx.x] = f[t];
     }
 }
 
+__global__ __launch_bounds__(SCAN_MAX_GROUPS) void jpeg_scan_carry_kernel(const int32_t* group_total, const int32_t* group_flag,
+                                                                         int32_t* carry, int n_groups) {
+    __shared__ int f[SCAN_MAX_GROUPS];
+    __shared__ int v[SCAN_MAX_GROUPS][4];
+    const int t = threadIdx.x;
+    f[t] = t < n_groups ? group_flag[t] : 0;
+    for (int i = 0; i < 4; ++i) v[t][i] = t < n_groups ? group_total[4 * t + i] : 0;
+    __syncthreads();
+    segmented_scan<SCAN_MAX_GROUPS>(f, v, t);
+    if (t < n_groups)
+        for (int i = 0; i < 4; ++i) carry[4 * t + i] = t ? v[t - 1][i] : 0;  // what enters workgroup t (inclusive up to t - 1)
+}
+
+// short_flag: a restart interval that holds fewer blocks than it must (a truncated or damaged stream)
 __global__ __launch_bounds__(DEC_WG) void jpeg_write_kernel(const JpegDev* hdr, const uint32_t* stream, long total_words,
-                                                           const int32_t* sub_seg, const uint32_t* in_state, const int32_t* base,
-                                                           int16_t* coef) {
+                                                           const int32_t* sub_seg, const uint32_t* in_state, const int32_t* excl,
+                                                           const int32_t* open, const int32_t* carry, const int32_t* out_nblk,
+                                                           int16_t* coef, int32_t* short_flag) {
     __shared__ DecLds L;
     const int sub0 = blockIdx.x * DEC_WG;
     dec_stage(L, hdr, stream, total_words, sub0);
-    const int t = threadIdx.x, s = sub0 + t;
-    if (s >= hdr->n_sub) return;
-    const long seg0 = long(sub_seg[s]) * hdr->seg_blocks;
+    const int t = threadIdx.x, s = sub0 + t, n_sub = hdr->n_sub;
+    if (s >= n_sub) return;
+    const int g = sub_seg[s];
+    const long seg0 = long(g) * hdr->seg_blocks;
     const long limit = min(seg0 + hdr->seg_blocks, long(hdr->total_blocks));
-    int n_blk, dc0 = base[4 * s + 1], dc1 = base[4 * s + 2], dc2 = base[4 * s + 3];
-    (void)dec_subsequence<true>(L, t, in_state[s], hdr->bpm, hdr->comp_packed, n_blk, dc0, dc1, dc2, coef, seg0 + base[4 * s], limit);
+    int base[4];
+    const int add = open[s];
+    for (int i = 0; i < 4; ++i) base[i] = excl[4 * s + i] + (add ? carry[4 * (s / SCAN_WG) + i] : 0);
+    if (s + 1 == n_sub || sub_seg[s + 1] != g) {
+        if (base[0] + out_nblk[s] < limit - seg0) atomicOr(short_flag, 1);
+    }
+    int n_blk, dc0 = base[1], dc1 = base[2], dc2 = base[3];
+    (void)dec_subsequence<true>(L, t, in_state[s], hdr->bpm, hdr->comp_packed, n_blk, dc0, dc1, dc2, coef, seg0 + base[0], limit);
 }
 
 // jidctint.c jpeg_idct_islow in 32-bit integers: one pass over eight values, DESCALE by SHIFT
@@ -689,10 +709,15 @@ __global__ __launch_bounds__(IDCT_BLOCKS * 8) void jpeg_idct_kernel(const JpegDe
     const long b0 = long(blockIdx.x) * IDCT_BLOCKS;
     const int total = hdr->total_blocks;
     {
+        // the decoder wrote zigzag order: the natural position on the way into LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(coef + b0 * 64);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(cs);
         const long avail = (long(total) - b0) * 32;  // words
-        for (int i = t; i < IDCT_BLOCKS * 32; i += IDCT_BLOCKS * 8) dst[i] = i < avail ? src[i] : 0u;
+        for (int i = t; i < IDCT_BLOCKS * 32; i += IDCT_BLOCKS * 8) {
+            const uint32_t v = i < avail ? src[i] : 0u;
+            const int bl = i >> 5, z = (i & 31) * 2;
+            cs[bl * 64 + hdr->nat[z]] = int16_t(v & 0xFFFFu);
+            cs[bl * 64 + hdr->nat[z + 1]] = int16_t(v >> 16);
+        }
         if (t < 3 * 64) qs[t] = (&hdr->quant[0][0])[t];
     }
     __syncthreads();
@@ -827,6 +852,12 @@ int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned
     const size_t o_blob = take(plan.stage_used);
     const size_t o_in = take(3 * n_sub * 4);
     const size_t o_out = take(n_sub * 4), o_nblk = take(n_sub * 4), o_dc = take(3 * n_sub * 4), o_base = take(4 * n_sub * 4);
+    const size_t n_groups = (n_sub + SCAN_WG - 1) / SCAN_WG;
+    if (n_groups > size_t(SCAN_MAX_GROUPS)) {
+        why = "entropy-coded segment too long";
+        return 2;
+    }
+    const size_t o_open = take(n_sub * 4), o_group = take(n_groups * (4 + 1 + 4) * 4);
     const size_t o_flags = take((MAX_ROUNDS + 8) * 4);
     const size_t o_coef = take(size_t(d.total_blocks) * 128);
     const size_t o_planes = take(plane_bytes + 16);
@@ -852,6 +883,10 @@ int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned
     auto* out_nblk = reinterpret_cast<int32_t*>(base + o_nblk);
     auto* out_dc = reinterpret_cast<int32_t*>(base + o_dc);
     auto* prefix = reinterpret_cast<int32_t*>(base + o_base);
+    auto* open = reinterpret_cast<int32_t*>(base + o_open);
+    auto* group_total = reinterpret_cast<int32_t*>(base + o_group);
+    auto* group_flag = group_total + 4 * n_groups;
+    auto* carry = group_flag + n_groups;
     auto* flags = reinterpret_cast<int32_t*>(base + o_flags);  // [round] "changed", [MAX_ROUNDS] "short"
     auto* coef = reinterpret_cast<int16_t*>(base + o_coef);
     uint8_t* planes = base + o_planes;
@@ -862,8 +897,10 @@ int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned
     MVLM_CHECK_HIP(ctx, hipMemsetAsync(coef, 0, size_t(d.total_blocks) * 128, stream));
     const unsigned dec_grid = unsigned((n_sub + DEC_WG - 1) / DEC_WG);
     int final_round = -1;
-    for (int r0 = 0; r0 < MAX_ROUNDS && final_round < 0; r0 += ROUNDS_PER_BATCH) {
-        for (int r = r0; r < r0 + ROUNDS_PER_BATCH; ++r) {
+    // a batch of rounds, then the host looks at the "changed" flags; rounds behind the final one return at once (5 us
+    // each), so the first batch is short (most textures need 6-12 rounds) and the later ones longer
+    for (int r0 = 0, batch = FIRST_BATCH; r0 < MAX_ROUNDS && final_round < 0; r0 += batch, batch = ROUNDS_PER_BATCH) {
+        for (int r = r0; r < r0 + batch; ++r) {
             const uint32_t* prev = in3 + size_t((r + 2) % 3) * n_sub;
             const uint32_t* cur = in3 + size_t(r % 3) * n_sub;
             uint32_t* next = in3 + size_t((r + 1) % 3) * n_sub;
@@ -871,9 +908,9 @@ int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned
                                next, out_state, out_nblk, out_dc, flags, r);
         }
         MVLM_CHECK_HIP(ctx, hipGetLastError());
-        MVLM_CHECK_HIP(ctx, hipMemcpyAsync(ctx->jpeg_flags_host + r0, flags + r0, ROUNDS_PER_BATCH * 4, hipMemcpyDeviceToHost, stream));
+        MVLM_CHECK_HIP(ctx, hipMemcpyAsync(ctx->jpeg_flags_host + r0, flags + r0, size_t(batch) * 4, hipMemcpyDeviceToHost, stream));
         MVLM_CHECK_HIP(ctx, hipStreamSynchronize(stream));
-        for (int r = r0; r < r0 + ROUNDS_PER_BATCH; ++r)
+        for (int r = r0; r < r0 + batch; ++r)
             if (ctx->jpeg_flags_host[r] == 0) {
                 final_round = r;
                 break;
@@ -885,8 +922,11 @@ int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned
         return 2;
     }
     const uint32_t* in_final = in3 + size_t(final_round % 3) * n_sub;
-    hipLaunchKernelGGL(jpeg_scan_kernel, dim3(1), dim3(1024), 0, stream, hdr, sub_seg, out_nblk, out_dc, prefix, flags + MAX_ROUNDS, plan.n_seg);
-    hipLaunchKernelGGL(jpeg_write_kernel, dim3(dec_grid), dim3(DEC_WG), 0, stream, hdr, words, total_words, sub_seg, in_final, prefix, coef);
+    hipLaunchKernelGGL(jpeg_scan_kernel, dim3(unsigned(n_groups)), dim3(SCAN_WG), 0, stream, hdr, sub_seg, out_nblk, out_dc, prefix, open,
+                       group_total, group_flag);
+    hipLaunchKernelGGL(jpeg_scan_carry_kernel, dim3(1), dim3(SCAN_MAX_GROUPS), 0, stream, group_total, group_flag, carry, int(n_groups));
+    hipLaunchKernelGGL(jpeg_write_kernel, dim3(dec_grid), dim3(DEC_WG), 0, stream, hdr, words, total_words, sub_seg, in_final, prefix, open,
+                       carry, out_nblk, coef, flags + MAX_ROUNDS);
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3(unsigned((d.total_blocks + IDCT_BLOCKS - 1) / IDCT_BLOCKS)), dim3(IDCT_BLOCKS * 8), 0, stream,
                        hdr, coef, planes);
     hipLaunchKernelGGL(jpeg_colour_kernel, dim3(unsigned((d.width + 1023) / 1024), unsigned(d.height)), dim3(256), 0, stream, hdr, planes, rgb_dev);

@@ -9,6 +9,6 @@ tail -8 $OUT/probe.txt
 rm -rf $OUT/prof
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/tools/probes/jpeg_profile.py > $OUT/profile_run.txt 2>&1 || { tail $OUT/profile_run.txt; exit 1; }
 grep "^rc" $OUT/profile_run.txt
-for f in $(find $OUT/prof -name '*kernel_stats.csv'); do cut -c1-200 $f | sed 's/(anonymous namespace):://g' | head -12 > $OUT/kernel_stats.txt; done
+for f in $(find $OUT/prof -name '*kernel_stats.csv'); do sed 's/(anonymous namespace):://g; s/([^"]*)//' $f | head -12 > $OUT/kernel_stats.txt; done
 cat $OUT/kernel_stats.txt
 find $OUT/prof -name '*kernel_trace.csv' -delete
