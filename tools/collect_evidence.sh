@@ -34,7 +34,7 @@ echo "== moment selection (fused) beside simple" ; date
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_96views.json 2> /dev/null || exit 1
 timeout -k 10 300 python3 bench.py --config dtu3d-geomdepth-96 --views-total 12 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_12views.json 2> /dev/null || exit 1
 echo "== ingest segments, per-level tables" ; date
-timeout -k 10 300 python3 tools/ingest_segments.py > $OUT/${TAG}_ingest_segments.txt 2>&1 || exit 1
+timeout -k 10 300 python3 tools/ingest_segments.py > $OUT/${TAG}_ingest_segments.txt 2>&1 || exit 1  # (JPEG on the device and on the host)
 for v in 8 12; do
   MVLM_BENCH_PER_LAYER=1 timeout -k 10 300 python3 bench.py --config dtu3d-geomdepth-96 --views-total $v --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_dtu3d_${v}views.json 2> $OUT/${TAG}_bench_dtu3d_${v}views.stderr.txt || exit 1
   python3 tools/per_level_table.py $OUT/${TAG}_bench_dtu3d_${v}views.stderr.txt > $OUT/${TAG}_per_level_${v}views.txt
@@ -66,6 +66,10 @@ P=$ROOT/gpurun_out/prof_${TAG}_12views
 cp $P/kernel_stats.csv $OUT/${TAG}_12views_kernel_stats.csv
 cp $P/pmc_summary.txt $OUT/${TAG}_12views_pmc_summary.txt
 cp $P/traffic.json $OUT/${TAG}_12views_traffic.json
+echo "== the device JPEG decoder: 528 files + four 2048^2 textures against Pillow, its kernels under rocprofv3" ; date
+timeout -k 10 600 bash tools/r5_jpeg.sh > $OUT/jpeg_log.txt 2>&1 || exit 1
+cp $ROOT/gpurun_out/jpeg/probe.txt $OUT/${TAG}_jpeg_probe.txt
+(cat $ROOT/gpurun_out/jpeg/kernel_stats.txt; grep "^rc" $ROOT/gpurun_out/jpeg/profile_run.txt) > $OUT/${TAG}_jpeg_kernel_stats.csv
 echo "== rasteriser alone (per-kernel times, six cases) and the kernels of configs[4]" ; date
 timeout -k 10 300 bash tools/raster_trace.sh raster_$TAG > /dev/null 2>&1 || exit 1
 (cat $ROOT/gpurun_out/raster_$TAG/bench.txt; echo; cat $ROOT/gpurun_out/raster_$TAG/kernels.txt) > $OUT/${TAG}_raster_trace.txt
