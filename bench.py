@@ -516,14 +516,26 @@ def main():
 
     if profile_in_timed:
         set_profiling(1)
+    # A full collection of the interpreter's oldest generation costs 40 ms in this process (the objects torch's import
+    # leaves behind); the set-up above allocates enough to make one due, and at 0.5 ms per step (configs[4]) it then lands
+    # in a 20-step timed region and quintuples it.  Collect here, outside; the collector stays ON during the timed steps.
+    import gc
+
+    gc.collect()
     barrier()
+    step_marks = [] if os.environ.get("MVLM_BENCH_STEP_TIMES") else None  # diagnostic: host time at the end of every timed step
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         if profile_in_timed:
             collect()
+        if step_marks is not None:
+            step_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if step_marks and rank == 0:
+        log("timed steps, ms between their returns: " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + step_marks, step_marks))
+            + f"; final wait {1e3 * (t0 + elapsed - step_marks[-1]):.2f}")
     if not profile_in_timed and rank == 0:
         set_profiling(1)
     if sharded:

@@ -331,7 +331,9 @@ void mvlm_jpeg_plan_dims(const MvlmJpegPlan& plan, int* width, int* height, int*
 
 // upper bound of what mvlm_jpeg_fill_stage writes
 size_t mvlm_jpeg_stage_bytes(const MvlmJpegPlan& plan, size_t n) {
-    const size_t stream = (n - plan.scan_begin) + size_t(plan.n_seg) * SUB_BYTES + 4 * SUB_BYTES;
+    // (a restart interval costs up to one subsequence of padding; there cannot be more intervals than two-byte markers)
+    const size_t intervals = std::min(size_t(plan.n_seg), (n - plan.scan_begin) / 2 + 1);
+    const size_t stream = (n - plan.scan_begin) + intervals * SUB_BYTES + 4 * SUB_BYTES;
     return 256 + (sizeof(JpegDev) + 255) / 256 * 256 + (stream + 255) / 256 * 256 + (stream / SUB_BYTES + 8) * 4;
 }
 
