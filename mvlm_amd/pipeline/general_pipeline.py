@@ -201,13 +201,18 @@ class Pipeline(abc.ABC):
         if not file_name.exists():
             print(f"File {file_name} does not exist")
             return None
-        # File ingest (OBJ parse, JPEG decode: host work, 3-20 ms per scan) runs BEFORE the pipeline lock is taken: the
-        # callers of a server's thread pool (3DMD_server.py:26-31) then parse their scans side by side and only the GPU
-        # section - RNG draws, device buffers, launch graphs, timings - is one caller at a time.
+        # File ingest (OBJ parse, JPEG read - or decode, with texture_decode="host" -: host work, 3-20 ms per scan) and the
+        # upload (pinned staging, the library's own copy stream, the JPEG's decode on the device) run BEFORE the pipeline
+        # lock is taken: the callers of a server's thread pool (3DMD_server.py:26-31) then ingest their scans side by side
+        # and only the GPU section - RNG draws, device buffers, launch graphs, timings - is one caller at a time.
         mesh, load_seconds = None, 0.0
         if self._fusable():
+            from ..utils.render3d import upload_mesh
+
             t0 = time.perf_counter()
             mesh = self.renderer_3d.load_mesh(self.renderer_3d._check_file(file_name), load_texture=self._texture_needed())
+            if mesh.n_tris > 0:
+                upload_mesh(self.renderer_3d.ctx, mesh)  # (thread-safe beside a launching thread: include/mvlm_hip.h)
             load_seconds = time.perf_counter() - t0
         with self._lock:
             self._rays = None

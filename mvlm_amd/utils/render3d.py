@@ -127,6 +127,9 @@ class HipRenderer3D:
         # "pre-align" block of a Deep-MVLM config (utils/prealign.py; utils3d.py:465-503): applied to every mesh this
         # renderer loads, the mesh handle it returns carries the matrix (Mesh.to_original)
         self.pre_align: dict | None = None
+        # where load_mesh's JPEG texture is decoded: "device" (the upload decodes the file's bytes on the GPU, csrc/jpeg.hip)
+        # or "host" (libjpeg through Pillow at load time); the pixels are the same bytes either way
+        self.texture_decode = "device"
         self.ctx = _lib.get_context(device)
 
     # ---- pose table (render3d.py:79-112) ----------------------------------------------
@@ -209,13 +212,13 @@ class HipRenderer3D:
 
     def load_mesh(self, file_name: Path, load_texture: bool = True) -> Mesh:
         """OBJ (+ texture) from disk, through the ``pre_align`` block when one is set.
-        ``load_texture=False`` leaves the JPEG alone: at 2048x2048 its decode (17 ms, single-threaded by format) is 6x the
-        parse of the geometry, and the consumer of a depth / geometry model's views reads no texture-shaded plane.  It is
+        ``load_texture=False`` leaves the JPEG alone (not even read), and the consumer of a depth / geometry model's views
+        reads no texture-shaded plane.  It is
         an argument of the call, decided by the caller that knows the consumer (``Pipeline._texture_needed``) - the
         renderer keeps no such state, so its public entry points load the texture like the reference (utils3d.py:26-36)."""
         from .prealign import aligned
 
-        return aligned(load_obj(file_name, load_texture=load_texture), self.pre_align)
+        return aligned(load_obj(file_name, load_texture=load_texture, decode=self.texture_decode), self.pre_align)
 
     def multiview_render_device(self, file_or_mesh, transformation_stack=None):
         """Same, but the image stack stays in HBM (used by the fused pipeline path)."""
