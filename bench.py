@@ -133,11 +133,11 @@ def ingest_figures(pipe, n_views: int, n_files: int = 12):
         done = sum(1 for _, lm in pipe.predict_files(files) if lm is not None)
         torch.cuda.synchronize()
         folder = (time.perf_counter() - t0) / done
-    log(f"with ingest: one file {1e3 * single:.1f} ms ({load_ms:.1f} ms of it OBJ parse + JPEG read; the JPEG is decoded on the device by the upload), "
+    log(f"with ingest: one file {1e3 * single:.1f} ms ({load_ms:.1f} ms of it ingest: OBJ parse, the JPEG decoded on the device by a second thread beside it, upload), "
         f"folder of {n_files}: {1e3 * folder:.1f} ms per scan ({1e3 * folder1:.1f} ms with one reader thread)")
     return {"single_file_views_per_s": round(n_views / single, 2), "folder_views_per_s": round(n_views / folder, 2),
             "folder_one_reader_views_per_s": round(n_views / folder1, 2), "unit": "views/s", "files": n_files,
-            "jpeg_decode": "device (mvlm_mesh_upload_jpeg)",
+            "jpeg_decode": "device, ahead of the mesh on a second thread (mvlm_texture_from_jpeg)",
             "note": "OBJ (6.4 MB text) parse, upload and the 2048x2048 JPEG texture's decode (on the GPU, byte for byte "
                     "libjpeg's pixels) included; folder = predict_files with the next scans' ingest on reader threads"}
 

@@ -36,6 +36,7 @@ extern "C" {
 
 typedef struct mvlm_ctx mvlm_ctx;
 typedef struct mvlm_mesh mvlm_mesh;
+typedef struct mvlm_texture mvlm_texture;
 
 #define MVLM_IMAGE_SIZE 256          /* render3d.py / general_pipeline.py:57 */
 #define MVLM_CONV_DESC_INTS 12       /* ints per conv slot, see mvlm_amd/weights.py */
@@ -103,6 +104,16 @@ int mvlm_jpeg_info(const uint8_t* jpeg_host, size_t n_bytes, int* width, int* he
 int mvlm_mesh_upload_jpeg(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
                           const int32_t* tris_host, int n_tris, const uint8_t* jpeg_host, size_t jpeg_bytes,
                           mvlm_mesh** out);
+/* The texture decoded AHEAD of its mesh, so that one thread can decode (GPU work + this thread waiting for it) while another
+ * still parses the geometry (obj_to_actor does both in sequence, utils3d.py:16-34): the pixels go into a device buffer of
+ * the context's mesh pool.  The handle is consumed by a successful mvlm_mesh_upload_texture that uses it (*consumed = 1; a
+ * mesh without texture coordinates does not use a texture, utils3d.py:26) and must be given back with mvlm_texture_free
+ * otherwise.  Return codes as mvlm_mesh_upload_jpeg (2 = not taken: decode on the host). */
+int mvlm_texture_from_jpeg(mvlm_ctx* ctx, const uint8_t* jpeg_host, size_t jpeg_bytes, mvlm_texture** out);
+int mvlm_texture_size(const mvlm_texture* tex, int* height, int* width);
+void mvlm_texture_free(mvlm_ctx* ctx, mvlm_texture* tex);
+int mvlm_mesh_upload_texture(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                             const int32_t* tris_host, int n_tris, mvlm_texture* tex, int* consumed, mvlm_mesh** out);
 /* the decoder alone: rgb_dev u8[H,W,3] (sizes from mvlm_jpeg_info) is complete when the call returns; rounds_out (may be
  * NULL): how many synchronisation rounds the parallel entropy decoder needed */
 int mvlm_jpeg_decode(mvlm_ctx* ctx, const uint8_t* jpeg_host, size_t jpeg_bytes, uint8_t* rgb_dev, int* rounds_out);

@@ -40,6 +40,11 @@ SIGNATURES = {
     "mvlm_jpeg_info": (C.c_int, [c_uint8_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "mvlm_mesh_upload_jpeg": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, c_int32_p, C.c_int, c_uint8_p, C.c_size_t,
                                         C.POINTER(C.c_void_p)]),
+    "mvlm_texture_from_jpeg": (C.c_int, [C.c_void_p, c_uint8_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mvlm_texture_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mvlm_texture_free": (None, [C.c_void_p, C.c_void_p]),
+    "mvlm_mesh_upload_texture": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, c_int32_p, C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "mvlm_jpeg_decode": (C.c_int, [C.c_void_p, c_uint8_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]),
     "mvlm_render": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_int, C.c_void_p]),
     "mvlm_render_check": (C.c_int, [C.c_void_p]),

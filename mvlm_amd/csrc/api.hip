@@ -128,11 +128,50 @@ extern "C" int mvlm_synchronize(mvlm_ctx* ctx) {
     return 0;
 }
 
+// A device buffer for `room` bytes on the upload path (caller holds ctx->mu): the OLDEST pooled buffer that fits - its
+// previous owner's work finished long ago, so the wait is a no-op and the copy really runs beside the current scan's
+// kernels - or a new allocation.  `waited`: the previous owner's event (goes back to the event list with the new owner).
+static bool take_upload_buffer(mvlm_ctx* ctx, size_t bytes, size_t room, void** p, size_t* cap, hipEvent_t* waited) {
+    int pick = -1;
+    for (int k = 0; k < int(ctx->mesh_pool.size()); ++k) {
+        const size_t c = ctx->mesh_pool[size_t(k)].cap;
+        if (c >= room && c <= 4 * bytes + (1u << 20)) {
+            pick = k;
+            break;
+        }
+    }
+    if (pick >= 0) {
+        const auto e = ctx->mesh_pool[size_t(pick)];
+        ctx->mesh_pool.erase(ctx->mesh_pool.begin() + pick);
+        ctx->mesh_pool_bytes -= e.cap;
+        *p = e.p;
+        *cap = e.cap;
+        *waited = e.freed;
+        return !(e.freed && hipStreamWaitEvent(ctx->upload_stream, e.freed, 0) != hipSuccess);
+    }
+    *cap = (room + 65535) / 65536 * 65536;
+    if (hipMalloc(p, *cap) != hipSuccess) {
+        *p = nullptr;
+        *cap = 0;
+        return false;
+    }
+    return true;
+}
+
+// a texture decoded ahead of its mesh (mvlm_texture_from_jpeg): the buffer a mesh upload takes over
+struct mvlm_texture {
+    uint8_t* dev = nullptr;
+    size_t cap = 0;
+    int h = 0, w = 0;
+    hipEvent_t waited = nullptr;
+};
+
 // jpeg != null: the texture is decoded on the device from the staged JPEG (jpeg.hip) instead of copied from tex_host;
+// pre != null: the texture is already on the device (mvlm_texture_from_jpeg) and its buffer becomes the mesh's;
 // returns 2 (and no mesh) when the stream turns out not to decode - the caller then decodes on the host
 static int mesh_upload_impl(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts, const int32_t* tris_host,
                             int n_tris, const uint8_t* tex_host, int tex_h, int tex_w, MvlmJpegPlan* jpeg,
-                            const uint8_t* jpeg_bytes, size_t jpeg_n, mvlm_mesh** out) {
+                            const uint8_t* jpeg_bytes, size_t jpeg_n, mvlm_mesh** out, mvlm_texture* pre = nullptr) {
     // Called from reader threads while another thread launches kernels on this context.  The host work - index
     // validation (O(3T)), waiting for a staging slot, a possible hipHostMalloc, the 10-25 MB memcpy into pinned memory -
     // runs under the upload mutex only; the context mutex every launch entry point takes is held just for the pool
@@ -140,12 +179,13 @@ static int mesh_upload_impl(mvlm_ctx* ctx, const float* verts_host, const float*
     MVLM_REQUIRE(ctx, out, "mesh_upload: null output");
     *out = nullptr;
     MVLM_REQUIRE(ctx, verts_host && tris_host && n_verts > 0 && n_tris > 0, "mesh_upload: mesh does not contain any points");
-    MVLM_REQUIRE(ctx, !(tex_host || jpeg) || (tex_h > 0 && tex_w > 0), "mesh_upload: bad texture size");
+    MVLM_REQUIRE(ctx, !(tex_host || jpeg || pre) || (tex_h > 0 && tex_w > 0), "mesh_upload: bad texture size");
     for (long i = 0; i < 3l * n_tris; ++i)
         MVLM_REQUIRE(ctx, tris_host[i] >= 0 && tris_host[i] < n_verts, "mesh_upload: triangle index out of range");
-    const bool with_tex = (tex_host || jpeg) && uvs_host;
+    const bool with_tex = (tex_host || jpeg || pre) && uvs_host;
     if (!with_tex) jpeg = nullptr;
-    const void* src[4] = {verts_host, uvs_host, tris_host, with_tex && !jpeg ? tex_host : nullptr};
+    if (!with_tex) pre = nullptr;  // (no texture coordinates: the texture is not used - utils3d.py:26; the caller keeps it)
+    const void* src[4] = {verts_host, uvs_host, tris_host, with_tex && !jpeg && !pre ? tex_host : nullptr};
     const size_t bytes[4] = {size_t(n_verts) * 12, uvs_host ? size_t(n_verts) * 8 : 0, size_t(n_tris) * 12,
                              with_tex ? size_t(tex_h) * tex_w * 3 : 0};
     // the rasteriser fetches a texel with one 4-byte load at byte 3 * index: 4 spare bytes behind the texture
@@ -193,32 +233,13 @@ static int mesh_upload_impl(mvlm_ctx* ctx, const float* verts_host, const float*
         std::lock_guard<std::mutex> lock(ctx->mu);  // pool, event list: shared with the launch entry points
         for (int i = 0; i < 4 && ok; ++i) {
             if (!bytes[i]) continue;
-            // the OLDEST pooled buffer that fits: its previous owner's work finished long ago, so the wait below is a no-op
-            // and the copy really runs beside the current scan's kernels
-            int pick = -1;
-            for (int k = 0; k < int(ctx->mesh_pool.size()); ++k) {
-                const size_t c = ctx->mesh_pool[size_t(k)].cap;
-                if (c >= room[i] && c <= 4 * bytes[i] + (1u << 20)) {
-                    pick = k;
-                    break;
-                }
+            if (i == 3 && pre) {  // decoded ahead: the texture's buffer becomes the mesh's
+                *dst[i] = pre->dev;
+                m->cap[i] = pre->cap;
+                m->waited[i] = pre->waited;
+                continue;
             }
-            if (pick >= 0) {
-                const auto e = ctx->mesh_pool[size_t(pick)];
-                ctx->mesh_pool.erase(ctx->mesh_pool.begin() + pick);
-                ctx->mesh_pool_bytes -= e.cap;
-                *dst[i] = e.p;
-                m->cap[i] = e.cap;
-                m->waited[i] = e.freed;  // returned to the event list with the mesh
-                if (e.freed && hipStreamWaitEvent(ctx->upload_stream, e.freed, 0) != hipSuccess) ok = false;
-            } else {
-                m->cap[i] = (room[i] + 65535) / 65536 * 65536;
-                if (hipMalloc(dst[i], m->cap[i]) != hipSuccess) {
-                    *dst[i] = nullptr;
-                    m->cap[i] = 0;
-                    ok = false;
-                }
-            }
+            if (!take_upload_buffer(ctx, bytes[i], room[i], dst[i], &m->cap[i], &m->waited[i])) ok = false;
             if (ok && src[i] && hipMemcpyAsync(*dst[i], stage + off[i], bytes[i], hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) ok = false;
         }
         if (with_tex) {
@@ -246,10 +267,15 @@ static int mesh_upload_impl(mvlm_ctx* ctx, const float* verts_host, const float*
     }
     if (!ok) {
         (void)hipStreamSynchronize(ctx->upload_stream);
+        if (pre) {  // still the caller's
+            m->tex = nullptr;
+            m->waited[3] = nullptr;
+        }
         mvlm_mesh_free(nullptr, m);
         if (jpeg_rc != 0) return jpeg_rc;  // (the message is set)
         return ctx->fail("mesh_upload: device allocation / copy failed");
     }
+    if (pre) delete pre;  // consumed: buffer and event are the mesh's now
     *out = m;
     return 0;
 }
@@ -330,6 +356,102 @@ extern "C" int mvlm_jpeg_decode(mvlm_ctx* ctx, const uint8_t* jpeg, size_t jpeg_
     const int rc = mvlm_jpeg_run(ctx, *plan, stage, rgb_dev, ctx->upload_stream, w, rounds_out);
     if (rc == 2) ctx->fail("jpeg: " + w);
     return rc;  // (mvlm_jpeg_run has waited for the stream: the staging slot is free, the image complete)
+}
+
+// The texture of a scan decoded AHEAD of its mesh, so that a caller can decode (GPU + this thread waiting for it) while
+// another thread still parses the geometry: the JPEG goes through the decoder into a buffer of the mesh pool; the handle is
+// consumed by mvlm_mesh_upload_texture or given back with mvlm_texture_free.  0 / 1 / 2 like mvlm_mesh_upload_jpeg.
+extern "C" int mvlm_texture_from_jpeg(mvlm_ctx* ctx, const uint8_t* jpeg, size_t jpeg_bytes, mvlm_texture** out) {
+    MVLM_REQUIRE(ctx, out, "texture_from_jpeg: null output");
+    *out = nullptr;
+    MVLM_REQUIRE(ctx, jpeg && jpeg_bytes > 0, "texture_from_jpeg: no JPEG");
+    std::unique_ptr<MvlmJpegPlan, void (*)(MvlmJpegPlan*)> plan(mvlm_jpeg_plan_new(), mvlm_jpeg_plan_delete);
+    std::string w;
+    if (mvlm_jpeg_plan_impl(jpeg, jpeg_bytes, *plan, w) != 0) {
+        ctx->fail("jpeg: " + w);
+        return 2;
+    }
+    int tw = 0, th = 0, nc = 0;
+    mvlm_jpeg_plan_dims(*plan, &tw, &th, &nc);
+    std::lock_guard<std::mutex> upload_lock(ctx->upload_mu);
+    MVLM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->upload_stream) MVLM_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    const size_t total = mvlm_jpeg_stage_bytes(*plan, jpeg_bytes);
+    const int slot = ctx->upload_stage_next;
+    ctx->upload_stage_next ^= 1;
+    if (ctx->upload_stage_done[slot]) MVLM_CHECK_HIP(ctx, hipEventSynchronize(ctx->upload_stage_done[slot]));
+    if (ctx->upload_stage_cap[slot] < total) {
+        if (ctx->upload_stage[slot]) (void)hipHostFree(ctx->upload_stage[slot]);
+        ctx->upload_stage[slot] = nullptr;
+        ctx->upload_stage_cap[slot] = 0;
+        const size_t cap = (total + (size_t(4) << 20)) / (size_t(4) << 20) * (size_t(4) << 20);
+        MVLM_CHECK_HIP(ctx, hipHostMalloc(&ctx->upload_stage[slot], cap, hipHostMallocDefault));
+        ctx->upload_stage_cap[slot] = cap;
+    }
+    auto* stage = static_cast<unsigned char*>(ctx->upload_stage[slot]);
+    if (mvlm_jpeg_fill_stage(*plan, jpeg, jpeg_bytes, stage, w) != 0) {
+        ctx->fail("jpeg: " + w);
+        return 2;
+    }
+    std::unique_ptr<mvlm_texture> t(new mvlm_texture());
+    t->h = th;
+    t->w = tw;
+    const size_t bytes = size_t(th) * tw * 3;
+    bool ok;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        void* p = nullptr;
+        ok = take_upload_buffer(ctx, bytes, bytes + 4, &p, &t->cap, &t->waited);  // (4 spare bytes: the rasteriser's texel load)
+        t->dev = static_cast<uint8_t*>(p);
+    }
+    int rc = ok ? mvlm_jpeg_run(ctx, *plan, stage, t->dev, ctx->upload_stream, w, nullptr) : 1;
+    if (rc != 0) {
+        if (rc == 2) ctx->fail("jpeg: " + w);
+        if (!ok) ctx->fail("texture_from_jpeg: device allocation failed");
+        mvlm_texture_free(ctx, t.release());
+        return rc;
+    }
+    *out = t.release();  // (mvlm_jpeg_run has waited for the stream: the pixels are there)
+    return 0;
+}
+
+extern "C" void mvlm_texture_free(mvlm_ctx* ctx, mvlm_texture* t) {
+    if (!t) return;
+    if (ctx && t->dev) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (t->waited) ctx->event_free.push_back(t->waited);
+        t->waited = nullptr;
+        if (ctx->mesh_pool.size() < 32 && ctx->mesh_pool_bytes + t->cap <= (size_t(1) << 30)) {
+            // only the upload stream has touched the buffer, and the decode waited for it: no event needed
+            ctx->mesh_pool.push_back({t->dev, t->cap, nullptr});
+            ctx->mesh_pool_bytes += t->cap;
+            t->dev = nullptr;
+        }
+    }
+    if (t->dev || t->waited) {
+        if (t->waited) (void)hipEventDestroy(t->waited);
+        if (t->dev) (void)hipFree(t->dev);
+    }
+    delete t;
+}
+
+extern "C" int mvlm_texture_size(const mvlm_texture* t, int* height, int* width) {
+    if (!t) return 1;
+    if (height) *height = t->h;
+    if (width) *width = t->w;
+    return 0;
+}
+
+// mvlm_mesh_upload with a texture that is on the device already; on success the handle is consumed (do not free it), on
+// failure it is still the caller's.  Without texture coordinates the texture is not used and stays the caller's too.
+extern "C" int mvlm_mesh_upload_texture(mvlm_ctx* ctx, const float* verts_host, const float* uvs_host, int n_verts,
+                                        const int32_t* tris_host, int n_tris, mvlm_texture* tex, int* consumed, mvlm_mesh** out) {
+    if (consumed) *consumed = 0;
+    MVLM_REQUIRE(ctx, tex && tex->dev, "mesh_upload_texture: no texture");
+    const bool will_consume = uvs_host != nullptr;
+    const int rc = mesh_upload_impl(ctx, verts_host, uvs_host, n_verts, tris_host, n_tris, nullptr, tex->h, tex->w, nullptr, nullptr, 0, out, tex);
+    if (rc == 0 && will_consume && consumed) *consumed = 1;
+    return rc;
 }
 
 // Buffers go back to the context's pool together with an event on the launch stream: whatever was enqueued for this

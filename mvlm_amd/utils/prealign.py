@@ -47,8 +47,12 @@ def apply_prealign(mesh: Mesh, cfg: dict) -> tuple[Mesh, np.ndarray]:
     m = prealign_matrix(mesh.verts, cfg)
     v = mesh.verts.astype(np.float64) @ m[:3, :3].T + m[:3, 3]
     # (a texture that is still the JPEG file's bytes stays that way: the upload decodes it on the device)
-    return Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, getattr(mesh, "_texture", None), mesh.path, to_original=m,
-                texture_jpeg=mesh.texture_jpeg), m
+    out = Mesh(v.astype(np.float32), mesh.tris, mesh.uvs, getattr(mesh, "_texture", None), mesh.path, to_original=m,
+               texture_jpeg=mesh.texture_jpeg)
+    out._texture_ahead = getattr(mesh, "_texture_ahead", None)  # (a texture decoded ahead moves to the copy that is uploaded)
+    if out._texture_ahead is not None:
+        mesh._texture_ahead = None
+    return out, m
 
 
 def aligned(mesh: Mesh, cfg: dict | None) -> Mesh:

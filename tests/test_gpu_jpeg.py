@@ -208,3 +208,61 @@ def test_folder_with_reader_threads_decodes_on_the_upload_stream(tmp_path):
         out = dict((str(p), lm) for p, lm in pipe.predict_files(files, readers=readers))
         for f, want in zip(files, single):
             assert np.array_equal(np.asarray(out[str(f)]), want), (readers, f.name)
+
+
+def test_texture_decoded_ahead_of_the_mesh(tmp_path):
+    """HipRenderer3D.load_mesh decodes the texture on the device on a second thread while the geometry is parsed
+    (mvlm_texture_from_jpeg); the mesh upload takes the buffer over (mvlm_mesh_upload_texture).  Same views as the host
+    decode; a handle nobody uploads is given back; a mesh without texture coordinates does not use (or consume) it."""
+    import gc
+
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.mesh_io import load_obj
+    from mvlm_amd.utils.render3d import decode_texture_ahead, upload_mesh
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    obj = write_face_like_obj(tmp_path / "face.obj", grid=61, tex_size=640, seed=8)
+    pipe = pipeline.create_pipeline("dtu3d", n_views=8, weights="synthetic:3", image_mode="RGB", verbose=False)
+    r3 = pipe.renderer_3d
+    poses = r3.generate_3d_transformations()
+    want = r3.render_device(load_obj(obj, decode="host"), poses).clone()
+    for _ in range(3):  # (buffers go through the mesh pool and come back)
+        mesh = r3.load_mesh(obj)
+        ahead = mesh._texture_ahead
+        assert ahead is not None and ahead.handle and mesh._texture is None and mesh.texture_jpeg is not None
+        got = r3.render_device(mesh, poses)
+        assert ahead.handle is None and mesh._texture_ahead is None and mesh._texture is None  # consumed, never decoded on the host
+        assert torch.equal(got, want)
+        del mesh
+    # never uploaded: the owner frees the device buffer
+    orphan = r3.load_mesh(obj)
+    assert orphan._texture_ahead.handle
+    del orphan
+    gc.collect()
+    # host decode asked for: no handle
+    r3.texture_decode = "host"
+    m = r3.load_mesh(obj)
+    assert getattr(m, "_texture_ahead", None) is None and m._texture is not None
+    assert torch.equal(r3.render_device(m, poses), want)
+    r3.texture_decode = "device"
+    # a texture for a mesh without texture coordinates: decoded, not used, still the caller's
+    plain = tmp_path / "plain.obj"
+    plain.write_text("v -50 -50 0\nv 50 -50 0\nv 0 50 10\nf 1 2 3\n")
+    loose = load_obj(plain)
+    loose._texture_ahead = decode_texture_ahead(r3.ctx, obj.with_suffix(".jpg").read_bytes())
+    keep = loose._texture_ahead
+    upload_mesh(r3.ctx, loose)
+    assert keep.handle, "a mesh without texture coordinates must not consume the texture"
+    img = r3.render_device(loose, poses)
+    fg = img[..., 3] < 1.0
+    assert bool(fg.any()) and bool((img[..., :3][fg] == 1.0).all())  # the white mesh of utils3d.py:58-64
+    del keep, loose
+    gc.collect()
+    # a progressive file: nothing ahead, the upload falls back to libjpeg
+    from PIL import Image
+
+    with Image.open(obj.with_suffix(".jpg")) as im:
+        im.save(obj.with_suffix(".jpg"), "JPEG", quality=90, progressive=True)
+    prog = r3.load_mesh(obj)
+    assert prog._texture_ahead is None and prog.texture_jpeg is not None
+    assert torch.equal(r3.render_device(prog, poses), r3.render_device(load_obj(obj, decode="host"), poses))

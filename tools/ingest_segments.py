@@ -53,4 +53,7 @@ def load_and_upload(mode):
     m = load_obj(obj, decode=mode); upload_mesh(ctx, m); torch.cuda.synchronize()
 print(f"load_obj + upload until done, JPEG on the host: {best(lambda: load_and_upload('host')):.2f} ms")
 print(f"load_obj + upload until done, JPEG on the device: {best(lambda: load_and_upload('device')):.2f} ms")
+def load_ahead_and_upload():
+    m = pipe.renderer_3d.load_mesh(obj); upload_mesh(ctx, m); torch.cuda.synchronize()
+print(f"HipRenderer3D.load_mesh + upload until done (JPEG decoded on the device by a second thread beside the OBJ parse): {best(load_ahead_and_upload):.2f} ms")
 print("texture file:", obj.with_suffix('.jpg').stat().st_size, "bytes")
