@@ -263,12 +263,14 @@ long usable_cpus() {
     return n < 1 ? 1 : n;
 }
 
+constexpr long MAX_READER_THREADS = 16;
+
 int reader_threads(size_t bytes) {
-    long want = long(bytes / (256u << 10));  // a thread per 256 KB of text, at most 8
+    long want = long(bytes / (256u << 10));  // a thread per 256 KB of text, at most MAX_READER_THREADS
     if (const char* e = getenv("MVLM_OBJ_THREADS")) want = strtol(e, nullptr, 10);
     static const long cpus = usable_cpus();
     if (!getenv("MVLM_OBJ_THREADS") && want > cpus) want = cpus;
-    return int(want < 1 ? 1 : want > 8 ? 8 : want);
+    return int(want < 1 ? 1 : want > MAX_READER_THREADS ? MAX_READER_THREADS : want);
 }
 
 // parse_chunk with the boundary's promise kept: nothing throws out of it (an allocation failure becomes the chunk's error)

@@ -42,7 +42,7 @@ def best(fn, n=7):
         t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
     return 1e3 * min(ts)
 print(f"native OBJ reader, default threads: {best(lambda: mesh_io._read_obj_native(obj)):.2f} ms")
-for n in ("1", "2", "4", "8"):
+for n in ("1", "2", "4", "8", "12", "16"):
     os.environ["MVLM_OBJ_THREADS"] = n
     print(f"native OBJ reader, {n} thread(s): {best(lambda: mesh_io._read_obj_native(obj)):.2f} ms")
 del os.environ["MVLM_OBJ_THREADS"]
