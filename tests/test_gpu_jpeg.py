@@ -116,13 +116,15 @@ def test_damaged_streams_never_take_the_gpu_down(ctx):
     plain = (JPEG / "c422_100x130_q95.jpg").read_bytes()
     sos = {id(d): d.index(b"\xff\xda") + 14 for d in (good, plain)}
     seen = set()
-    for trial in range(60):
+    for trial in range(400):
         src = good if trial % 2 else plain
         d = bytearray(src)
         kind = trial % 4
         if kind == 0:  # a few flipped bytes
             for _ in range(1 + trial % 5):
                 d[rng.integers(sos[id(src)], len(d) - 2)] ^= int(rng.integers(1, 256))
+            if trial % 16 == 0:  # ... and in the tables too (the header still parses or the file is refused up front)
+                d[rng.integers(20, sos[id(src)] - 14)] ^= int(rng.integers(1, 256))
         elif kind == 1:  # truncated
             d = d[:rng.integers(sos[id(src)], len(d) - 2)]
         elif kind == 2:  # a run of zeros
