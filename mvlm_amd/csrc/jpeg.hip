@@ -120,6 +120,10 @@ int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::
         why = "not a JPEG stream";
         return 2;
     }
+    if (n >= (size_t(1) << 30)) {
+        why = "file too large";
+        return 2;
+    }
     JpegDev& d = plan.dev;
     std::memset(&d, 0, sizeof(d));
     uint16_t quant[4][64];
@@ -371,6 +375,10 @@ int mvlm_jpeg_fill_stage(MvlmJpegPlan& plan, const uint8_t* data, size_t n, uint
             const size_t pad = (SUB_BYTES - o % SUB_BYTES) % SUB_BYTES;
             std::memset(out + o, 0xFF, pad);
             o += pad;
+            if (int32_t(o / SUB_BYTES) == seg_first.back()) {
+                why = "an empty restart interval";
+                return 2;
+            }
             seg_first.push_back(int32_t(o / SUB_BYTES));
             p += 2;
         } else if (nxt == 0xFF) {
@@ -381,6 +389,10 @@ int mvlm_jpeg_fill_stage(MvlmJpegPlan& plan, const uint8_t* data, size_t n, uint
     }
     if (seg + 1 != plan.n_seg) {
         why = "fewer restart markers than restart intervals";
+        return 2;
+    }
+    if (int32_t((o + SUB_BYTES - 1) / SUB_BYTES) == seg_first.back()) {
+        why = seg ? "an empty restart interval" : "empty scan";
         return 2;
     }
     const size_t pad = (SUB_BYTES - o % SUB_BYTES) % SUB_BYTES + 2 * SUB_BYTES;

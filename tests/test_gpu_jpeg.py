@@ -308,3 +308,21 @@ def test_server_threads_with_device_decoded_textures(tmp_path):
         # neighbouring consensus - never on another scan's geometry (a mixed-up texture or mesh would move all of them)
         d = np.linalg.norm(lm - want[name], axis=1)
         assert np.median(d) < 1e-6, (k, name, float(np.median(d)))
+
+
+def test_restart_markers_that_do_not_match_the_header(ctx):
+    """Restart intervals that are empty, missing or too many: not taken (2), never a picture with silently missing blocks."""
+    src = (JPEG / "c420_80x96_restart3.jpg").read_bytes()
+    first = src.index(b"\xff\xd0")
+    second = src.index(b"\xff\xd1", first)
+    empty = src[:first + 2] + src[second:]                       # RST0 RST1 back to back
+    missing = src[:first] + src[first + 2:]                      # one marker gone: the two intervals run together
+    extra = src[:first] + b"\xff\xd0" + src[first:]              # one marker too many
+    tail = src[:src.rindex(b"\xff\xd9")]
+    last_rst = max(tail.rfind(bytes([0xFF, 0xD0 + i])) for i in range(8))
+    empty_last = src[:last_rst + 2] + b"\xff\xd9"                # the last interval holds nothing
+    for name, data in (("empty", empty), ("missing", missing), ("extra", extra), ("empty_last", empty_last)):
+        got, rc, why, _ = _decode(ctx, data)
+        assert rc == 2 and got is None and why, (name, rc, why)
+    got, rc, _, _ = _decode(ctx, src)
+    assert rc == 0 and np.array_equal(got, np.load(JPEG / "expected.npz")["c420_80x96_restart3"])
