@@ -165,6 +165,10 @@ int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::
                 }
                 for (int i = 0; i < 64; ++i) {
                     quant[tq][kNatural[i]] = pq ? uint16_t(rd16(seg + q + 2 * i)) : seg[q + i];
+                    if (quant[tq][kNatural[i]] > 255) {  // (the 32-bit inverse DCT here is exact for 8-bit tables only)
+                        why = "quantisation table with 16-bit entries";
+                        return 2;
+                    }
                 }
                 q += pq ? 128 : 64;
                 have_q[tq] = true;

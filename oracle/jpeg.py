@@ -75,6 +75,8 @@ def parse(data: bytes) -> dict:
                     q += 128
                 if len(tab) != 64 or tq > 3:
                     raise Unsupported("bad DQT")
+                if tab.max() > 255:
+                    raise Unsupported("quantisation table with 16-bit entries")
                 nat = np.zeros(64, np.int32)
                 nat[NATURAL_ORDER] = tab  # the file holds zigzag order
                 quant[tq] = nat
