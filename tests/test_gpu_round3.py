@@ -118,21 +118,40 @@ def test_depth_models_skip_the_texture_decode(tmp_path, monkeypatch):
     from mvlm_amd.utils.synthetic import write_face_like_obj
 
     obj = write_face_like_obj(tmp_path / "face.obj", grid=40, tex_size=64, seed=1)
-    asked = []
-    real_load = render3d.load_obj
+    asked = []  # per load: did anything touch the texture file (libjpeg at load time, or - round 5 - the device decoder)?
+    real_load, real_ahead = render3d.load_obj, render3d.decode_texture_ahead
+    touched = []
 
     def spy(path, load_texture=True, **kw):
-        asked.append(bool(load_texture))
-        return real_load(path, load_texture=load_texture, **kw)
+        mesh = real_load(path, load_texture=load_texture, **kw)
+        touched.append(bool(load_texture) and (mesh.texture_jpeg is not None or mesh._texture is not None))
+        return mesh
+
+    def spy_ahead(ctx, data):
+        touched.append(True)
+        return real_ahead(ctx, data)
+
+    real_load_mesh = render3d.HipRenderer3D.load_mesh
+
+    def spy_load_mesh(self, file_name, load_texture=True):
+        touched.clear()
+        mesh = real_load_mesh(self, file_name, load_texture=load_texture)
+        asked.append(any(touched))
+        assert asked[-1] == bool(load_texture)
+        return mesh
 
     monkeypatch.setattr(render3d, "load_obj", spy)
+    monkeypatch.setattr(render3d, "decode_texture_ahead", spy_ahead)
+    monkeypatch.setattr(render3d.HipRenderer3D, "load_mesh", spy_load_mesh)
     pipe = pipeline.create_pipeline("bu3dfe", n_views=8, weights="synthetic:3", image_mode="depth", verbose=False)
     np.random.seed(5)
     lean = pipe.predict_one_file(obj)
     assert pipe._texture_needed() is False and asked == [False]
     # direct use of the same renderer afterwards: texture loaded (the reference's behaviour, utils3d.py:26-36)
     assert pipe.renderer_3d.load_mesh(obj).texture is not None
+    asked.clear()
     stack, _, handle = pipe.renderer_3d.multiview_render(obj)
+    assert asked == [True]
     assert handle.texture is not None and len(np.unique(stack[..., :3])) > 2
     asked.clear()
     pipe.render_image_stack, pipe.render_image_folder = True, tmp_path
