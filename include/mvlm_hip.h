@@ -20,9 +20,11 @@
  *     calls predict_one_file from a thread pool without locks, 3DMD_server.py:26-31);
  *     one C call is atomic, a SEQUENCE of calls that shares buffers is the caller's to
  *     order (the Python Pipeline holds a lock of its own around a whole scan).
- *     mvlm_mesh_upload may run on other threads beside the launching one: its host work
- *     happens outside the ctx mutex.  mvlm_obj_read / mvlm_mesh_read need no ctx at all
- *     (mvlm_obj_read parses on up to 8 threads of its own; MVLM_OBJ_THREADS overrides).
+ *     The mvlm_mesh_upload* / mvlm_texture_* / mvlm_jpeg_decode calls may run on other threads
+ *     beside the launching one: their host work and their device work (a copy / decode stream
+ *     of the context's own) happen outside the ctx mutex, under an upload mutex of their own.
+ *     mvlm_obj_read / mvlm_mesh_read / mvlm_jpeg_info need no ctx at all
+ *     (mvlm_obj_read parses on up to 16 threads of its own; MVLM_OBJ_THREADS overrides).
  */
 #ifndef MVLM_HIP_H
 #define MVLM_HIP_H
