@@ -130,6 +130,10 @@ int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, in
  * three planes) for models trained on geometry renderings - the reference's renderer has no such
  * mode, parity unpinned. */
 int mvlm_set_render_shading(mvlm_ctx* ctx, int shading);
+/* The one rasterisation parameter OpenGL leaves to the implementation that is a NUMBER: vertices snap to 2^-bits pixel
+ * (GL_SUBPIXEL_BITS; the reference's images depend on the OpenGL its VTK runs on, render3d.py:60-65).  8 (default) = what
+ * GPUs report; 4 = the standard's minimum and the software OpenGL tests/golden/gl_raster.npz was drawn with.  4..8. */
+int mvlm_set_render_subpixel_bits(mvlm_ctx* ctx, int bits);
 /* HIP-event timing of the render kernels (bench.py's rasteriser roofline): while enabled every mvlm_render
  * records one {n_views, n_verts, n_tris, ms}; get_profile waits for the stream, fills up to `cap` records,
  * clears them and returns the count (-1 on failure). */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mvlm_render_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_render_get_profile": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, C.c_int]),
     "mvlm_set_render_shading": (C.c_int, [C.c_void_p, C.c_int]),
+    "mvlm_set_render_subpixel_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_cnn_load": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_int32_p, C.c_int, C.c_int, C.c_int]),
     "mvlm_cnn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "mvlm_cnn_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -60,14 +60,14 @@ __device__ inline rm_vert load_vert(const vert12* __restrict__ p, int i) {
 }
 
 __global__ void transform_kernel(const float* __restrict__ verts, int n_verts, const double* __restrict__ rot,
-                                 int n_views, vert12* __restrict__ tv) {
+                                 int n_views, int sub_bits, vert12* __restrict__ tv) {
     int view, chunk;
     if (!view_chunk((n_verts + 255) / 256, n_views, &view, &chunk)) return;
     const int v = chunk * 256 + int(threadIdx.x);
     if (v >= n_verts) return;
     double m[9];
     for (int k = 0; k < 9; ++k) m[k] = rot[view * 9 + k];
-    const rm_vert o = rm_transform(m, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
+    const rm_vert o = rm_transform(m, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2], sub_bits);
     vert12 w;
     w.X = o.X;
     w.Y = o.Y;
@@ -135,7 +135,7 @@ __device__ inline int edge24(int32_t ax, int32_t ay, int32_t bx, int32_t by, int
     *w = e;
     if (e > 0) return 1;
     if (e < 0) return 0;
-    return dy > 0 || (dy == 0 && dx > 0);
+    return RM_OWNS(dx, dy);
 }
 
 // rm_cover for a pixel centre inside the triangle's bounding box (T: tri24, or an rm_tri of small extent)
@@ -433,7 +433,7 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
         MVLM_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
     hipLaunchKernelGGL(transform_kernel, dim3(view_chunk_grid((V + 255) / 256, n_views)), dim3(256), 0, ctx->stream,
-                       mesh->verts, V, rot, n_views, tv);
+                       mesh->verts, V, rot, n_views, ctx->render_subpixel_bits, tv);
     hipLaunchKernelGGL(classify_kernel<CLASSIFY_TPT>, dim3(view_chunk_grid((T + 256 * CLASSIFY_TPT - 1) / (256 * CLASSIFY_TPT), n_views)), dim3(256), 0,
                        ctx->stream, tv, mesh->tris, V, T, n_views, keys, counts, n_big, big_list);
     hipLaunchKernelGGL(scan_kernel, dim3(n_views), dim3(TILES), 0, ctx->stream, counts, offsets, cap, overflow);
@@ -491,6 +491,13 @@ extern "C" int mvlm_render_get_profile(mvlm_ctx* ctx, int32_t* n_views, int32_t*
     ctx->render_prof.clear();
     ctx->render_event_cursor = 0;
     return n;
+}
+
+extern "C" int mvlm_set_render_subpixel_bits(mvlm_ctx* ctx, int bits) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, bits >= 4 && bits <= 8, "render: subpixel bits must be 4..8 (GL_SUBPIXEL_BITS of the OpenGL to match; 8 = GPUs)");
+    ctx->render_subpixel_bits = bits;
+    return 0;
 }
 
 extern "C" int mvlm_set_render_shading(mvlm_ctx* ctx, int shading) {

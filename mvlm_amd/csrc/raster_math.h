@@ -42,20 +42,24 @@ typedef struct {
     float pad;
 } rm_vert;
 
-RM_FN rm_vert rm_transform(const double* m /*[9] row-major*/, float vx, float vy, float vz) {
+/* `sub_bits`: vertices snap to 2^-sub_bits pixel (GL_SUBPIXEL_BITS of the OpenGL to be matched: 8 on GPUs, the default; >= 4
+ * by the standard).  The lattice stays 1/256 pixel: a coarser snap is a multiple of it, every integer below scales by a
+ * power of two and every float made from a ratio of them is unchanged. */
+RM_FN rm_vert rm_transform(const double* m /*[9] row-major*/, float vx, float vy, float vz, int sub_bits) {
     const double x = vx, y = vy, z = vz;
     const float xv = (float)((m[0] * x + m[1] * y) + m[2] * z);
     const float yv = (float)((m[3] * x + m[4] * y) + m[5] * z);
     const float zv = (float)((m[6] * x + m[7] * y) + m[8] * z);
     const float k = 256.0f / 300.0f;
-    float fx = floorf(((xv + 150.0f) * k) * 256.0f + 0.5f);
-    float fy = floorf(((yv + 150.0f) * k) * 256.0f + 0.5f);
-    const float lim = (float)RM_COORD_LIM;
+    const float sub = (float)(1 << sub_bits);
+    float fx = floorf(((xv + 150.0f) * k) * sub + 0.5f);
+    float fy = floorf(((yv + 150.0f) * k) * sub + 0.5f);
+    const float lim = (float)(RM_COORD_LIM >> (8 - sub_bits));
     fx = fx < -lim ? -lim : (fx > lim ? lim : fx);
     fy = fy < -lim ? -lim : (fy > lim ? lim : fy);
     rm_vert o;
-    o.X = (int32_t)fx;
-    o.Y = (int32_t)fy;
+    o.X = (int32_t)fx * (RM_SUB >> sub_bits);
+    o.Y = (int32_t)fy * (RM_SUB >> sub_bits);
     o.z = (500.0f - zv) / 1500.0f;
     o.pad = 0.0f;
     return o;
@@ -106,6 +110,11 @@ RM_FN rm_tri rm_setup(rm_vert a, rm_vert b, rm_vert c) {
     return t;
 }
 
+/* A pixel centre exactly on the directed edge (dx,dy) of a counter-clockwise triangle (y up) belongs to the triangle whose
+ * LEFT or BOTTOM edge that is: the top-left rule in the flipped image the reference returns.  OpenGL leaves the choice open;
+ * this is the rule of the OpenGL implementation the contract was checked against (tests/golden/gl_raster.npz). */
+#define RM_OWNS(dx, dy) ((dy) < 0 || ((dy) == 0 && (dx) > 0))
+
 /* edge function for the directed edge (ax,ay)->(bx,by) at point (px,py) plus the
  * ownership rule for points exactly on the edge */
 RM_FN int rm_edge(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t px, int32_t py, int64_t* w) {
@@ -114,7 +123,7 @@ RM_FN int rm_edge(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t px, in
     *w = e;
     if (e > 0) return 1;
     if (e < 0) return 0;
-    return dy > 0 || (dy == 0 && dx > 0);
+    return RM_OWNS(dx, dy);
 }
 
 /* coverage + barycentric weights of pixel (i,j) (j counts up from the bottom row) */
@@ -131,8 +140,12 @@ RM_FN int rm_cover(const rm_tri* t, int i, int j, float* b0, float* b1, float* b
     return 1;
 }
 
+/* a vertex attribute at a covered pixel: the plane through vertex 0, as a GL rasteriser evaluates it - a constant
+ * attribute stays constant bit for bit (coplanar screen-parallel triangles tie exactly and LEQUAL decides; a triangle with
+ * one texture coordinate has one texel) */
 RM_FN float rm_interp(float b0, float b1, float b2, float a0, float a1, float a2) {
-    return (b0 * a0 + b1 * a1) + b2 * a2;
+    (void)b0;
+    return a0 + (b1 * (a1 - a0) + b2 * (a2 - a0));
 }
 
 /* depth-test key: smaller wins; equal depth -> later triangle wins (GL_LEQUAL) */

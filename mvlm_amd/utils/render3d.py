@@ -145,7 +145,7 @@ class HipRenderer3D:
                  min_x_angle: int = -40, max_x_angle: int = 40, min_y_angle: int = -80, max_y_angle: int = 80,
                  min_z_angle: int = -20, max_z_angle: int = 20, min_scale: float = 1.4, max_scale: float = 1.9,
                  min_tx: int = -20, max_tx: int = 20, min_ty: int = -20, max_ty: int = 20, device: int = 0,
-                 verbose: bool = True, shading: str = "texture"):
+                 verbose: bool = True, shading: str = "texture", subpixel_bits: int = 8):
         if tuple(image_size) != (256, 256):
             raise ValueError("the HIP renderer is built for 256x256 views (general_pipeline.py:57)")
         self.n_views = n_views
@@ -164,6 +164,11 @@ class HipRenderer3D:
             raise ValueError("shading must be 'texture' (the reference's unlit render) or 'geometry'")
         # "geometry": build-defined shaded plane for models trained on geometry renderings
         self.shading = shading
+        # vertex snap of the rasteriser, 2^-bits pixel: GL_SUBPIXEL_BITS of the OpenGL whose images are to be matched (the
+        # reference's pixels depend on it; 8 = GPUs, 4 = the software GL behind tests/golden/gl_raster.npz)
+        if subpixel_bits not in (4, 5, 6, 7, 8):
+            raise ValueError("subpixel_bits must be 4..8")
+        self.subpixel_bits = int(subpixel_bits)
         # "pre-align" block of a Deep-MVLM config (utils/prealign.py; utils3d.py:465-503): applied to every mesh this
         # renderer loads, the mesh handle it returns carries the matrix (Mesh.to_original)
         self.pre_align: dict | None = None
@@ -206,6 +211,7 @@ class HipRenderer3D:
         handle = upload_mesh(self.ctx, mesh)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         self.ctx.check(self.ctx.lib.mvlm_set_render_shading(self.ctx.handle, 1 if self.shading == "geometry" else 0))
+        self.ctx.check(self.ctx.lib.mvlm_set_render_subpixel_bits(self.ctx.handle, self.subpixel_bits))
         self.ctx.check(self.ctx.lib.mvlm_render(self.ctx.handle, handle, _lib.as_ptr(rot, C.c_double), n,
                                                 C.c_void_p(out.data_ptr())))
         return out

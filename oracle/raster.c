@@ -32,15 +32,16 @@
 
 typedef struct { int32_t x, y; float z; } SV;
 
-static SV project(const double* m, const float* v) {
+static SV project(const double* m, const float* v, int bits) {
     double x = v[0], y = v[1], z = v[2];
     float xv = (float)((m[0] * x + m[1] * y) + m[2] * z);
     float yv = (float)((m[3] * x + m[4] * y) + m[5] * z);
     float zv = (float)((m[6] * x + m[7] * y) + m[8] * z);
     const float k = 256.0f / 300.0f;
-    float fx = floorf(((xv + 150.0f) * k) * 256.0f + 0.5f);
-    float fy = floorf(((yv + 150.0f) * k) * 256.0f + 0.5f);
-    const float lim = 4194304.0f;
+    const float sub = (float)(1 << bits); /* 256: the contract's 1/256 pixel */
+    float fx = floorf(((xv + 150.0f) * k) * sub + 0.5f);
+    float fy = floorf(((yv + 150.0f) * k) * sub + 0.5f);
+    const float lim = (float)(1 << (14 + bits)); /* 16384 pixels */
     if (fx < -lim) fx = -lim;
     if (fx > lim) fx = lim;
     if (fy < -lim) fy = -lim;
@@ -57,9 +58,12 @@ static int64_t orient(SV a, SV b, int32_t px, int32_t py) {
     return (int64_t)(b.x - a.x) * (py - a.y) - (int64_t)(b.y - a.y) * (px - a.x);
 }
 
-static int owns(SV a, SV b) { /* who gets a pixel centre lying exactly on edge a->b */
+/* who gets a pixel centre lying exactly on edge a->b of a counter-clockwise triangle (y up): the triangle whose LEFT or
+ * BOTTOM edge it is - the top-left rule in the flipped image the reference returns.  OpenGL leaves the choice to the
+ * implementation; this is what the GL this contract was checked against does (tests/golden/gl_raster.npz). */
+static int owns(SV a, SV b) {
     int32_t dx = b.x - a.x, dy = b.y - a.y;
-    return dy > 0 || (dy == 0 && dx > 0);
+    return dy < 0 || (dy == 0 && dx > 0);
 }
 
 static int32_t fdiv(int32_t a, int32_t b) {
@@ -83,8 +87,14 @@ static int geometry_u8(SV a, SV b, SV c) {
     return (int)((fabsf(nz) / len) * 255.0f + 0.5f);
 }
 
-int oracle_render(const float* verts, const float* uvs, int n_verts, const int32_t* tris, int n_tris,
-                  const uint8_t* tex, int th, int tw, const double* rot, int n_views, int shading, float* out) {
+/* `subpixel_bits`: the vertex lattice is 2^-bits pixel.  The contract (and the HIP rasteriser) is 8 - what GPUs report as
+ * GL_SUBPIXEL_BITS; OpenGL only demands >= 4, and the software GL that tests/golden/gl_raster.npz was drawn with
+ * (tools/make_gl_golden.py) uses 4, so the comparison with it runs this same code at 4. */
+int oracle_render_bits(const float* verts, const float* uvs, int n_verts, const int32_t* tris, int n_tris,
+                       const uint8_t* tex, int th, int tw, const double* rot, int n_views, int shading, int subpixel_bits,
+                       float* out) {
+    const int32_t S = 1 << subpixel_bits, H = S / 2;
+    if (subpixel_bits < 1 || subpixel_bits > 8 || (shading == 1 && subpixel_bits != 8)) return 2; /* geometry_u8 is in 1/256 px */
     SV* sv = (SV*)malloc(sizeof(SV) * (size_t)n_verts);
     float* zbuf = (float*)malloc(sizeof(float) * N * N);
     int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * N * N);
@@ -92,7 +102,7 @@ int oracle_render(const float* verts, const float* uvs, int n_verts, const int32
     if (!sv || !zbuf || !owner || !bary) return 1;
     for (int view = 0; view < n_views; ++view) {
         const double* m = rot + 9 * view;
-        for (int i = 0; i < n_verts; ++i) sv[i] = project(m, verts + 3 * i);
+        for (int i = 0; i < n_verts; ++i) sv[i] = project(m, verts + 3 * i, subpixel_bits);
         for (int p = 0; p < N * N; ++p) {
             zbuf[p] = 2.0f;
             owner[p] = -1;
@@ -117,8 +127,8 @@ int oracle_render(const float* verts, const float* uvs, int n_verts, const int32
             if (c.y < miny) miny = c.y;
             if (b.y > maxy) maxy = b.y;
             if (c.y > maxy) maxy = c.y;
-            int i0 = -fdiv(-(minx - 128), 256), i1 = fdiv(maxx - 128, 256);
-            int j0 = -fdiv(-(miny - 128), 256), j1 = fdiv(maxy - 128, 256);
+            int i0 = -fdiv(-(minx - H), S), i1 = fdiv(maxx - H, S);
+            int j0 = -fdiv(-(miny - H), S), j1 = fdiv(maxy - H, S);
             if (i0 < 0) i0 = 0;
             if (j0 < 0) j0 = 0;
             if (i1 > N - 1) i1 = N - 1;
@@ -126,14 +136,16 @@ int oracle_render(const float* verts, const float* uvs, int n_verts, const int32
             const float fa = (float)area;
             for (int j = j0; j <= j1; ++j)
                 for (int i = i0; i <= i1; ++i) {
-                    int32_t px = i * 256 + 128, py = j * 256 + 128;
+                    int32_t px = i * S + H, py = j * S + H;
                     int64_t w0 = orient(b, c, px, py), w1 = orient(c, a, px, py), w2 = orient(a, b, px, py);
                     if (w0 < 0 || w1 < 0 || w2 < 0) continue;
                     if (w0 == 0 && !owns(b, c)) continue;
                     if (w1 == 0 && !owns(c, a)) continue;
                     if (w2 == 0 && !owns(a, b)) continue;
                     float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
-                    float z = (b0 * a.z + b1 * b.z) + b2 * c.z;
+                    /* attributes as a plane through vertex a (what a GL rasteriser evaluates): a constant attribute stays
+                     * constant bit for bit, so coplanar screen-parallel triangles tie exactly and LEQUAL decides */
+                    float z = a.z + (b1 * (b.z - a.z) + b2 * (c.z - a.z));
                     if (!(z >= 0.0f && z <= 1.0f)) continue;
                     int p = j * N + i;
                     if (z <= zbuf[p]) {
@@ -159,8 +171,10 @@ int oracle_render(const float* verts, const float* uvs, int n_verts, const int32
                         r = g = bl = (float)geometry_u8(sv[ia], sv[ib], sv[ic]);
                     } else if (tex && uvs) {
                         float b0 = bary[3 * p], b1 = bary[3 * p + 1], b2 = bary[3 * p + 2];
-                        float u = (b0 * uvs[2 * ia] + b1 * uvs[2 * ib]) + b2 * uvs[2 * ic];
-                        float v = (b0 * uvs[2 * ia + 1] + b1 * uvs[2 * ib + 1]) + b2 * uvs[2 * ic + 1];
+                        float u0 = uvs[2 * ia], v0 = uvs[2 * ia + 1];
+                        float u = u0 + (b1 * (uvs[2 * ib] - u0) + b2 * (uvs[2 * ic] - u0));
+                        float v = v0 + (b1 * (uvs[2 * ib + 1] - v0) + b2 * (uvs[2 * ic + 1] - v0));
+                        (void)b0;
                         float uu = u - floorf(u), vv = v - floorf(v);
                         int tx = (int)(uu * (float)tw), ty = (int)(vv * (float)th);
                         if (tx > tw - 1) tx = tw - 1;
@@ -184,4 +198,9 @@ int oracle_render(const float* verts, const float* uvs, int n_verts, const int32
     free(owner);
     free(bary);
     return 0;
+}
+
+int oracle_render(const float* verts, const float* uvs, int n_verts, const int32_t* tris, int n_tris,
+                  const uint8_t* tex, int th, int tw, const double* rot, int n_views, int shading, float* out) {
+    return oracle_render_bits(verts, uvs, n_verts, tris, n_tris, tex, th, tw, rot, n_views, shading, 8, out);
 }

@@ -29,11 +29,13 @@ def _load():
             build()
         _lib = C.CDLL(str(_SO))
         _lib.oracle_render.restype = C.c_int
+        _lib.oracle_render_bits.restype = C.c_int
     return _lib
 
 
-def multiview_render(verts, tris, uvs, texture, transform_stack, shading: str = "texture") -> np.ndarray:
-    """-> image_stack [N,256,256,4] float32 in [0,1] (render3d.py:179-193 output)."""
+def multiview_render(verts, tris, uvs, texture, transform_stack, shading: str = "texture", subpixel_bits: int = 8) -> np.ndarray:
+    """-> image_stack [N,256,256,4] float32 in [0,1] (render3d.py:179-193 output).  `subpixel_bits`: see oracle_render_bits
+    (8 = the contract; 4 only for the comparison with the software OpenGL of tests/golden/gl_raster.npz)."""
     lib = _load()
     verts = np.ascontiguousarray(verts, np.float32)
     tris = np.ascontiguousarray(tris, np.int32)
@@ -44,10 +46,10 @@ def multiview_render(verts, tris, uvs, texture, transform_stack, shading: str = 
     uv = np.ascontiguousarray(uvs, np.float32) if uvs is not None else None
     tex = np.ascontiguousarray(texture, np.uint8) if use_tex else None
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None
-    rc = lib.oracle_render(p(verts, C.c_float), p(uv, C.c_float), C.c_int(verts.shape[0]), p(tris, C.c_int32),
+    rc = lib.oracle_render_bits(p(verts, C.c_float), p(uv, C.c_float), C.c_int(verts.shape[0]), p(tris, C.c_int32),
                            C.c_int(tris.shape[0]), p(tex, C.c_uint8), C.c_int(tex.shape[0] if use_tex else 0),
                            C.c_int(tex.shape[1] if use_tex else 0), p(rot, C.c_double), C.c_int(n),
-                           C.c_int(1 if shading == "geometry" else 0), p(out, C.c_float))
+                           C.c_int(1 if shading == "geometry" else 0), C.c_int(subpixel_bits), p(out, C.c_float))
     if rc != 0:
         raise MemoryError("oracle_render failed")
     return out
