@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mvlm_hip.h"
+#include "jpeg_plan.h"
 
 #define MVLM_CHECK_HIP(ctx, expr)                                                            \
     do {                                                                                     \
@@ -241,6 +242,7 @@ struct mvlm_ctx {
     int conv_force_variant = -1;            // >= 0: mvlm_conv_bench times exactly this kernel variant
     std::vector<ConvOverride> conv_overrides;  // tools/tune_in_network.py: kernel variant per (shape, kind), before any table
     unsigned long long conv_attr_mask = 0;  // conv variants whose launch attributes are set on this ctx's device
+    int render_subpixel_bits = 8;  // vertex snap 2^-bits pixel (GL_SUBPIXEL_BITS of the OpenGL to match)
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render
     bool render_profiling = false;        // mvlm_render_set_profiling: HIP events around each render's kernels
@@ -316,14 +318,7 @@ inline int mvlm_mesh_wait_ready(mvlm_ctx* ctx, const mvlm_mesh* m, hipStream_t s
     return 0;
 }
 
-// jpeg.hip
-struct MvlmJpegPlan;
-int mvlm_jpeg_plan_impl(const uint8_t* data, size_t n, MvlmJpegPlan& plan, std::string& why);
-void mvlm_jpeg_plan_dims(const MvlmJpegPlan& plan, int* width, int* height, int* components);
-MvlmJpegPlan* mvlm_jpeg_plan_new();
-void mvlm_jpeg_plan_delete(MvlmJpegPlan* p);
-size_t mvlm_jpeg_stage_bytes(const MvlmJpegPlan& plan, size_t n);
-int mvlm_jpeg_fill_stage(MvlmJpegPlan& plan, const uint8_t* data, size_t n, uint8_t* stage, std::string& why);
+// jpeg.hip (the host parser and its declarations: jpeg_plan.h / jpeg_plan.cpp)
 int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned, uint8_t* rgb_dev, hipStream_t stream,
                   std::string& why, int* rounds_out);
 
