@@ -18,8 +18,8 @@ With N GPUs the SAME 96 views are sharded 96/N per rank (strong scaling - BASELI
 before fusion; `--scaling weak` keeps 96 views per GPU instead.  Other BASELINE configurations:
 `--config dtu3d-rgb-64 | bu3dfe-depth-8 | dtu3d-geomdepth-96 | mediapipe-478x128`.
 
-roofline.traffic (HBM bytes per launch of the dominant kernel) is measured by the N = 1 invocation itself with two short
-rocprofv3 --pmc child passes after the timed region (live_counters: HBM bytes and MFMA-busy of the dominant kernel); --no-live-traffic / MVLM_BENCH_LIVE_TRAFFIC=0 quote the
+roofline.traffic (HBM bytes per launch of the dominant kernel) is measured by the N = 1 invocation itself with three short
+rocprofv3 --pmc child passes after the timed region (each at most 90 s, 150 s together; the timed result is logged first) (live_counters: HBM bytes and MFMA-busy of the dominant kernel); --no-live-traffic / MVLM_BENCH_LIVE_TRAFFIC=0 quote the
 committed profiles/rNN_traffic.json instead.
 
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
@@ -56,6 +56,23 @@ DEFAULT_CONFIG = "bu3dfe-rgbd-96"
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def stage(what: str) -> None:
+    """A rank's last stage reached, for the launcher's diagnosis when a multi-rank start stalls (launch_ranks): one small file
+    per rank in the directory the launcher names; nothing when the bench runs without that launcher."""
+    d = os.environ.get("MVLM_BENCH_STATUS_DIR")
+    if not d:
+        return
+    try:
+        with open(os.path.join(d, f"rank{os.environ.get('RANK', '0')}"), "w") as f:
+            f.write(json.dumps({"stage": what, "t": round(time.time(), 3), "pid": os.getpid(),
+                                "local_rank": os.environ.get("LOCAL_RANK"), "backend": os.environ.get("MVLM_BENCH_BACKEND", "nccl"),
+                                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                                "visible": {k: os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+                                            if os.environ.get(k) is not None}}))
+    except OSError:
+        pass
 
 
 def host_cores() -> int:
@@ -202,9 +219,13 @@ def live_counters(variant_name: str | None, argv: list[str]):
     import csv
     import re
     import shutil
+    import signal
     import subprocess
     import tempfile
 
+    PASS_LIMIT = float(os.environ.get("MVLM_BENCH_PMC_PASS_LIMIT", "90"))
+    BUDGET = float(os.environ.get("MVLM_BENCH_PMC_BUDGET", "150"))
+    t_budget_end = time.time() + BUDGET
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists():
         return {"error": "rocprofv3 not found"}
@@ -222,8 +243,31 @@ def live_counters(variant_name: str | None, argv: list[str]):
         env = dict(os.environ, MVLM_BENCH_NO_INGEST="1", MVLM_BENCH_CHILD="1", TMPDIR="/tmp")
         cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                str(Path(__file__).resolve())] + argv + ["--steps", "1", "--warmup", "0", "--cpu-views", "0", "--no-fast-mode"]
+        # A pass takes ~3 s; the timed result exists already and must not be lost to a stalled profiler: each pass gets at most
+        # PASS_LIMIT seconds and all of them together BUDGET.  rocprofv3 and the python under it run in a session of their
+        # own, so that a timeout ends BOTH (killing rocprofv3 alone would leave its python holding the GPU).
+        left = min(PASS_LIMIT, t_budget_end - time.time())
+        if left <= 1.0:
+            shutil.rmtree(out, ignore_errors=True)
+            return {"error": f"no time left for the rocprofv3 {'+'.join(counters)} pass ({BUDGET:.0f} s for all passes)"}
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                child.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                for sig in (signal.SIGTERM, signal.SIGKILL):
+                    try:
+                        os.killpg(child.pid, sig)
+                    except ProcessLookupError:
+                        break
+                    try:
+                        child.communicate(timeout=10)
+                        break
+                    except subprocess.TimeoutExpired:
+                        continue
+                shutil.rmtree(out, ignore_errors=True)
+                return {"error": f"rocprofv3 {'+'.join(counters)} pass stopped after {left:.0f} s"}
+            r = child
         except Exception as e:  # noqa: BLE001
             shutil.rmtree(out, ignore_errors=True)
             return {"error": f"rocprofv3 {'+'.join(counters)} pass failed: {e}"}
@@ -290,8 +334,13 @@ def launch_ranks(n: int) -> int:
     127.0.0.1 --master-port <free> bench.py <same arguments>` - relay rank 0's ONE JSON line to stdout, the
     children's stderr to stderr, and return their exit code.  Nothing here makes a HIP call or imports torch: the GPUs are
     counted from sysfs (visible_gpus)."""
+    import queue
+    import shutil
+    import signal
     import socket
     import subprocess
+    import tempfile
+    import threading
 
     share = os.environ.get("MVLM_BENCH_SHARE_GPU") == "1"
     have = visible_gpus()
@@ -308,7 +357,7 @@ def launch_ranks(n: int) -> int:
         log(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have} "
             f"(MVLM_BENCH_SHARE_GPU=1 rehearses the {n}-rank path with every rank on GPU 0 over gloo)")
         return 2
-    if have < 1:
+    if have < 1 and not os.environ.get("MVLM_BENCH_TEST_FAULT"):   # (the launcher's own CPU tests start ranks that never reach a GPU call)
         log("bench.py: no GPU visible")
         return 2
     with socket.socket() as s:
@@ -322,22 +371,78 @@ def launch_ranks(n: int) -> int:
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    log("bench.py: starting", " ".join(cmd))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    line = None
-    for out in proc.stdout:
-        out = out.rstrip("\n")
+    # The ranks must not outlive the caller's patience silently: the first multi-rank RCCL start on a node is the one step
+    # nobody could rehearse, and "killed at the limit, wrote nothing" is its least useful outcome.  The whole run gets a
+    # deadline below the driver's ten minutes; each rank's process-group start its own, shorter one (main: init timeout).
+    deadline_s = float(os.environ.get("MVLM_BENCH_DEADLINE", "480"))
+    status_dir = tempfile.mkdtemp(prefix="mvlm_bench_status_")
+    env["MVLM_BENCH_STATUS_DIR"] = status_dir
+    log("bench.py: starting", " ".join(cmd), f"(deadline {deadline_s:.0f} s)")
+    t_start = time.time()
+    # a session of their own: on a deadline the launcher, its ranks and anything they started go together
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    lines: "queue.Queue[str | None]" = queue.Queue()
+
+    def pump():
+        for out in proc.stdout:
+            lines.put(out.rstrip("\n"))
+        lines.put(None)
+
+    threading.Thread(target=pump, daemon=True).start()
+    line, timed_out = None, False
+    while True:
+        left = t_start + deadline_s - time.time()
+        if left <= 0:
+            timed_out = True
+            break
+        try:
+            out = lines.get(timeout=min(left, 5.0))
+        except queue.Empty:
+            continue
+        if out is None:
+            break
         if out.startswith("{") and '"metric"' in out:
             line = out
         elif out:
             log(out)  # anything else a rank or the launcher wrote to stdout
-    rc = proc.wait()
-    if line is not None:
+    if timed_out:
+        log(f"bench.py: the {n} ranks did not finish within {deadline_s:.0f} s (MVLM_BENCH_DEADLINE) - stopping them")
+        for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(proc.pid, sig)   # fresh children of this process, in their own session: never this process itself
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=wait)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    else:
+        rc = proc.wait()
+    if line is not None and not timed_out:
         print(line, flush=True)
     elif rc == 0:
         log("bench.py: the ranks exited cleanly without a result line")
         rc = 1
+    if rc != 0:
+        diagnose_ranks(status_dir, n, t_start)
+    shutil.rmtree(status_dir, ignore_errors=True)
     return rc
+
+
+def diagnose_ranks(status_dir: str, n: int, t_start: float) -> None:
+    """One line per rank on stderr: how far it got (bench.stage), with what backend and device environment - and what to try."""
+    for r in range(n):
+        try:
+            rec = json.loads(Path(status_dir, f"rank{r}").read_text())
+            log(f"bench.py: rank {r}: last stage '{rec['stage']}' reached {rec['t'] - t_start:.1f} s after the start; backend {rec['backend']}, "
+                f"HSA_ENABLE_IPC_MODE_LEGACY={rec['HSA_ENABLE_IPC_MODE_LEGACY']}, local rank {rec['local_rank']}, device variables {rec['visible'] or 'unset'}, pid {rec['pid']}")
+        except (OSError, ValueError, KeyError):
+            log(f"bench.py: rank {r}: never reported (the process did not start, or died while importing)")
+    log("bench.py: a rank that stops in 'init_process_group (nccl)' or 'first barrier' could not connect RCCL: check that every rank has "
+        "HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) and its own GPU; MVLM_BENCH_BACKEND=gloo runs the same sharded step with the two small "
+        "collectives staged through the host; MVLM_BENCH_INIT_TIMEOUT / MVLM_BENCH_DEADLINE (seconds) move the two limits")
 
 
 def main():
@@ -357,7 +462,7 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true", help=argparse.SUPPRESS)  # old name of the default
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra pass that measures the opt-in fast precision")
     ap.add_argument("--no-live-traffic", action="store_true",
-                    help="quote roofline.traffic from the committed PMC profile instead of measuring it with two rocprofv3 --pmc child passes")
+                    help="quote roofline.traffic from the committed PMC profile instead of measuring it with three rocprofv3 --pmc child passes")
     ap.add_argument("--precision", default="exact", choices=["exact", "fast", "fast16"], help=argparse.SUPPRESS)  # experiments: time the fast path as the main loop
     ap.add_argument("--selection", default="simple", choices=["simple", "moment"],
                     help="heatmap maxima (paulsenpredictor.py:112-158): the argmax pixel (default) or the 31x31 centroid around it - both fused")
@@ -384,16 +489,32 @@ def main():
     share_gpu = os.environ.get("MVLM_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    use_gloo = share_gpu or os.environ.get("MVLM_BENCH_BACKEND") == "gloo"
+    stage("torch imported")
     backend = "none"
     # MVLM_BENCH_FORCE_DIST=1: take the multi-rank path (process group, sharded pipeline, collectives) with whatever
     # world size there is - under torch.distributed.run --nproc-per-node 1 this rehearses RCCL itself on a one-GPU box
     sharded = world > 1 or (os.environ.get("MVLM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if not (sharded and use_gloo):
+        torch.cuda.set_device(local_rank)   # (RCCL is created on this rank's device; gloo connects before any GPU call)
+        stage("device set")
     if sharded and world == 1:
         os.environ["MVLM_DIST_WORLD_OF_ONE"] = "1"  # mvlm_amd.parallel then runs its collectives in the group of one
     if sharded:
+        from datetime import timedelta
+
         import torch.distributed as dist
 
+        # A process group that cannot connect must say so soon: the default limit of the "nccl" backend is ten minutes - the
+        # driver's whole window for this script.  The launcher (launch_ranks) has its own deadline above this one.
+        init_timeout = timedelta(seconds=float(os.environ.get("MVLM_BENCH_INIT_TIMEOUT", "120")))
+        fault = os.environ.get("MVLM_BENCH_TEST_FAULT", "")   # tests/test_distributed_cpu.py only: "exit:<rank>" / "hang:<rank>"
+        if fault.endswith(f":{rank}"):
+            stage(f"test fault '{fault}' before init_process_group")
+            if fault.startswith("exit"):
+                log(f"bench.py: rank {rank}: MVLM_BENCH_TEST_FAULT={fault}: leaving before the process group exists")
+                sys.exit(3)
+            time.sleep(3600)
         # the communication libraries may log to fd 1 while they connect (gloo does): stdout is reserved for
         # the ONE JSON line, so fd 1 points at stderr until the process group exists
         sys.stdout.flush()
@@ -402,16 +523,26 @@ def main():
         try:
             # MVLM_BENCH_BACKEND=gloo: one rank per GPU as always, the two small collectives of a step staged through the host
             # (a way around an RCCL that will not initialise on some node; the default is RCCL = backend "nccl")
-            if share_gpu or os.environ.get("MVLM_BENCH_BACKEND") == "gloo":
-                dist.init_process_group("gloo")
+            stage(f"init_process_group ({'gloo' if use_gloo else 'nccl'})")
+            if use_gloo:
+                dist.init_process_group("gloo", timeout=init_timeout)
             else:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=init_timeout)
+            stage("first barrier")
             dist.barrier()
+        except Exception as e:  # noqa: BLE001
+            log(f"bench.py: rank {rank}: the process group did not come up within {init_timeout.total_seconds():.0f} s "
+                f"(MVLM_BENCH_INIT_TIMEOUT): {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}")
+            raise
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
         backend = f"{dist.get_backend()} world_size {dist.get_world_size()}"
+        stage("process group up")
+        if use_gloo:
+            torch.cuda.set_device(local_rank)
+            stage("device set")
 
     from mvlm_amd import arch, config, parallel, weights
     from mvlm_amd.utils.synthetic import face_like_mesh
@@ -442,6 +573,7 @@ def main():
             # raw one that block is written for, brought into the view box the way the product does at load time
             mesh = aligned(unaligned_copy(mesh, pipe.pre_align), pipe.pre_align)
             log(f"pre-align block of {spec['json']} applied: {cfg.pre_align}")
+    stage("pipeline built")
     np.random.seed(0)
     poses = pipe.renderer_3d.generate_3d_transformations() if rank == 0 else None
     poses = parallel.broadcast_array(poses, (n_total, 6), device=local_rank)
@@ -473,6 +605,7 @@ def main():
     r_ctx = pipe.renderer_3d.ctx
     # set-up, not warm-up: the product captures its launch graph on the second pass over a set of buffers and replays it
     # from the third; with fewer than three warm-up steps the capture would fall into the timed region
+    stage("warm-up steps")
     for _ in range(max(0, 3 - args.warmup)):
         step()
     for _ in range(args.warmup):
@@ -522,7 +655,9 @@ def main():
     import gc
 
     gc.collect()
+    stage("barrier before the timed region")
     barrier()
+    stage("timed steps")
     step_marks = [] if os.environ.get("MVLM_BENCH_STEP_TIMES") else None  # diagnostic: host time at the end of every timed step
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -533,6 +668,7 @@ def main():
             step_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    stage("after the timed region (profiling passes)")
     if step_marks and rank == 0:
         log("timed steps, ms between their returns: " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + step_marks, step_marks))
             + f"; final wait {1e3 * (t0 + elapsed - step_marks[-1]):.2f}")
@@ -659,7 +795,9 @@ def main():
         # rasteriser: HBM-bound.  Algorithmic bytes per view: mesh read V*20 B + T*12 B,
         # framebuffer write 256^2 * 16 B, one 3-byte texel per pixel at most
         ras_bytes_view = mesh.n_verts * 20 + mesh.n_tris * 12 + 256 * 256 * 16 + 256 * 256 * 3
-        # HBM traffic of this invocation's kernels by counters (two short rocprofv3 child passes), else the committed profile's
+        # the timed result goes to stderr before anything else can delay or lose it (the JSON line follows the profiler passes)
+        log(f"timed region: {views_per_s:.2f} views/s, {1e3 * elapsed / args.steps:.3f} ms per step over {args.steps} steps ({n_total} views, {world} rank(s))")
+        # HBM traffic of this invocation's kernels by counters (three short rocprofv3 child passes), else the committed profile's
         live = None
         # (not when this process itself runs under a profiler: its preloaded tool library would be inherited by the children)
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
