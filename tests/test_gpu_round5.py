@@ -213,7 +213,7 @@ def test_four_ranks_at_the_twelve_view_shard_size_equal_the_single_process(tmp_p
     (gloo; all ranks on device 0), 48 views.  Every rank must return, bit for bit, what a single process returns that pushes
     the same views through the network 12 at a time (the device batch selects the kernel tiles, i.e. the order of the fp32
     sums: include/mvlm_hip.h).  (bench.py --gpus 5 - five ranks and a launcher that never opens the card - is rehearsed in
-    tools/r5_rehearsal.sh.)"""
+    tools/rehearsal.sh.)"""
     import socket
 
     import torch.multiprocessing as mp

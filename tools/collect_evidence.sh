@@ -42,7 +42,7 @@ done
 MVLM_BENCH_PER_LAYER=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > /dev/null 2> $OUT/per_layer_96.err || exit 1
 python3 tools/per_level_table.py $OUT/per_layer_96.err > $OUT/${TAG}_per_level_96views.txt
 echo "== bench.py --gpus 5 as a plain process (five gloo ranks sharing this GPU: the box's process guard admits six processes), configs[2] / [3] / [4] at the 8-GPU shard sizes" ; date
-timeout -k 10 900 bash tools/r5_rehearsal.sh $TAG > $OUT/rehearsal_log.txt 2>&1 || exit 1
+timeout -k 10 900 bash tools/rehearsal.sh $TAG > $OUT/rehearsal_log.txt 2>&1 || exit 1
 cp $ROOT/gpurun_out/rehearsal_$TAG/${TAG}_rehearsal_5ranks_*.json $OUT/
 fi
 if [[ $PART == *b* ]]; then
@@ -67,13 +67,13 @@ cp $P/kernel_stats.csv $OUT/${TAG}_12views_kernel_stats.csv
 cp $P/pmc_summary.txt $OUT/${TAG}_12views_pmc_summary.txt
 cp $P/traffic.json $OUT/${TAG}_12views_traffic.json
 echo "== the device JPEG decoder: 528 files + four 2048^2 textures against Pillow, its kernels under rocprofv3" ; date
-timeout -k 10 600 bash tools/r5_jpeg.sh > $OUT/jpeg_log.txt 2>&1 || exit 1
+timeout -k 10 600 bash tools/jpeg_evidence.sh > $OUT/jpeg_log.txt 2>&1 || exit 1
 cp $ROOT/gpurun_out/jpeg/probe.txt $OUT/${TAG}_jpeg_probe.txt
 (cat $ROOT/gpurun_out/jpeg/kernel_stats.txt; grep "^rc" $ROOT/gpurun_out/jpeg/profile_run.txt) > $OUT/${TAG}_jpeg_kernel_stats.csv
 echo "== rasteriser alone (per-kernel times, six cases) and the kernels of configs[4]" ; date
 timeout -k 10 300 bash tools/raster_trace.sh raster_$TAG > /dev/null 2>&1 || exit 1
 (cat $ROOT/gpurun_out/raster_$TAG/bench.txt; echo; cat $ROOT/gpurun_out/raster_$TAG/kernels.txt) > $OUT/${TAG}_raster_trace.txt
-timeout -k 10 300 bash tools/probes/profile_mediapipe_config.sh > /dev/null 2>&1 || exit 1
+timeout -k 10 300 bash tools/mediapipe_kernel_stats.sh > /dev/null 2>&1 || exit 1
 cut -c1-260 $ROOT/gpurun_out/mp478/kernel_stats.csv | head -24 > $OUT/${TAG}_mediapipe_kernel_stats.csv
 fi
 date; ls -la $OUT

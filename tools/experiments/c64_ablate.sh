@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiments on the 64-channel tile (conv3x3_c64_t8x32, 18 % of the 96-view step) and the dominant 128-channel
-# tile: builds with parts of the kernel switched off (wrong results, timing only).  usage: tools/c64_ablate.sh
+# tile: builds with parts of the kernel switched off (wrong results, timing only).  usage: tools/experiments/c64_ablate.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/mvlm_amd/csrc

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiments on the opt-in split kernels (62 bf16x3, 61 f16x2) (run on the GPU box): builds of conv_fast.hip with parts switched off
-# (wrong results, timing only) against the real one, on the dominant layer shapes.  usage: tools/fast_ablate.sh
+# (wrong results, timing only) against the real one, on the dominant layer shapes.  usage: tools/experiments/fast_ablate.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/mvlm_amd/csrc

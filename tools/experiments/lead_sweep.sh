@@ -1,5 +1,5 @@
 #!/bin/bash
-# MFMAs issued before a k-step's share of the staging work (MVLM_MFMA_LEAD): sweep on the big tiles.  usage: tools/lead_sweep.sh
+# MFMAs issued before a k-step's share of the staging work (MVLM_MFMA_LEAD): sweep on the big tiles.  usage: tools/experiments/lead_sweep.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/mvlm_amd/csrc

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where the waves of the dominant tiles wait, from SQ counters (run on the GPU box).  PC sampling is not available on
 # this pool (gpurun refuses --pc-sampling-beta-enabled), so stall attribution stays at the counter level:
-# separate --pmc passes with --kernel-trace only.  usage: tools/pmc_stalls.sh
+# separate --pmc passes with --kernel-trace only.  usage: tools/experiments/pmc_stalls.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_stalls

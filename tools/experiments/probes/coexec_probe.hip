@@ -2,7 +2,7 @@
 // instruction stream overlap on gfx950, i.e. could a convolution kernel add VALU FMAs on top of its matrix
 // pipe work?  For V = 0..32 v_fma_f32 placed after every MFMA it reports the kernel time, the MFMA rate and
 // the combined (MFMA + VALU) f32 rate.
-// build: hipcc -O3 --offload-arch=gfx950 tools/probes/coexec_probe.hip -o /tmp/coexec_probe
+// build: hipcc -O3 --offload-arch=gfx950 tools/experiments/probes/coexec_probe.hip -o /tmp/coexec_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

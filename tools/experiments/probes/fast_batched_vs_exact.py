@@ -4,7 +4,7 @@ predict_files(batch_scans=4), separately and together, 6 scans at 8 views - how 
 import sys, tempfile
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from mvlm_amd import pipeline
 from mvlm_amd.utils.synthetic import write_face_like_obj
 d = Path(tempfile.mkdtemp())

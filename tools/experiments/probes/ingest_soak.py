@@ -2,7 +2,7 @@
 import resource, sys, tempfile, time
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from mvlm_amd import pipeline
 from mvlm_amd.utils.synthetic import write_face_like_obj
 d = Path(tempfile.mkdtemp())

@@ -11,7 +11,7 @@ from PIL import Image, ImageFile
 
 ImageFile.MAXBLOCK = 1 << 25  # (optimize=True needs the whole file in one encoder buffer)
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from mvlm_amd import _lib  # noqa: E402
 
 ctx = _lib.Context(0)

@@ -2,7 +2,7 @@
 import ctypes as C, sys, tempfile, time
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from mvlm_amd import _lib
 from mvlm_amd.utils.synthetic import write_face_like_obj
 ctx = _lib.Context(0); lib = ctx.lib

@@ -1,6 +1,6 @@
 // Layout and rate of v_mfma_f32_4x4x1_16b_f32 on gfx950 (16 independent 4x4 blocks per instruction): which lane feeds which
 // row / column, where the results land, and cycles per instruction next to v_mfma_f32_32x32x2_f32.
-// build: hipcc -O3 --offload-arch=gfx950 tools/probes/mfma4x4_probe.hip -o /tmp/mfma4x4_probe
+// build: hipcc -O3 --offload-arch=gfx950 tools/experiments/probes/mfma4x4_probe.hip -o /tmp/mfma4x4_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

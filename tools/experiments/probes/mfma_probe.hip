@@ -1,5 +1,5 @@
 // Micro-benchmark: what limits a v_mfma_f32_32x32x2_f32 stream fed from LDS on gfx950?
-// build: hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_probe.hip -o /tmp/mfma_probe
+// build: hipcc -O3 --offload-arch=gfx950 tools/experiments/probes/mfma_probe.hip -o /tmp/mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,7 +1,7 @@
 """Phases of the native OBJ reader on the bench's 6.4 MB file (MVLM_OBJ_TIMING=1)."""
 import os, sys, tempfile, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from mvlm_amd.utils.synthetic import write_face_like_obj
 from mvlm_amd.utils import mesh_io
 d = Path(tempfile.mkdtemp())

@@ -3,7 +3,7 @@
 import cProfile, pstats, sys, io, time
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 sys.argv = ["bench.py"]
 import bench
 from mvlm_amd import pipeline

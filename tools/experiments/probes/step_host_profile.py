@@ -4,7 +4,7 @@ steps' GPU work goes."""
 import cProfile, pstats, sys, io
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from mvlm_amd import config
 from mvlm_amd.utils.synthetic import face_like_mesh
 cfg = config.load_config(config.default_config("DTU3D", "geometry+depth", n_views=12))

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r4a
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 120 tools/probes/bin/xcd_barrier_probe > $OUT/xcd_barrier_probe.txt 2>&1 || exit 1
+timeout -k 10 120 tools/experiments/probes/bin/xcd_barrier_probe > $OUT/xcd_barrier_probe.txt 2>&1 || exit 1
 # c128_t8x32 (variant 0) on 256 / 512 / 768 / 1024 tiles: what does the half-empty last round of 768 tiles cost?
 timeout -k 10 300 python3 tools/conv_shape_bench.py 4,256,128,128,3,0 8,256,128,128,3,0 12,256,128,128,3,0 16,256,128,128,3,0 \
    4,128,128,128,3,0 8,128,128,128,3,0 12,128,128,128,3,0 16,128,128,128,3,0 \

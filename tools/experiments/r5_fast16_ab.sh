@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the f16x2 kernel's tile forms inside the network (real data): MVLM_FAST16_HALF_TILES = 0 full tiles (round 4), 1 half
-# tiles for the 128-channel layers, 3 for the 64-channel layers too.  usage: tools/r5_fast16_ab.sh "0 1 3"
+# tiles for the 128-channel layers, 3 for the 64-channel layers too.  usage: tools/experiments/r5_fast16_ab.sh "0 1 3"
 set -u
 export MVLM_BENCH_LIVE_TRAFFIC=0
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of experimental builds of conv_fast.hip inside the network (real data: the clock under load is part of the result):
-# usage: tools/r5_fast_exp.sh "NONE SETPRIO ..."  -> bench.py --precision fast16 per build
+# usage: tools/experiments/r5_fast_exp.sh "NONE SETPRIO ..."  -> bench.py --precision fast16 per build
 set -u
 export MVLM_BENCH_LIVE_TRAFFIC=0
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiments on the split-K tiles of the small hourglass levels (run on the GPU box): builds of the split-K
-# instantiation units with parts of the kernel switched off (wrong results, timing only).  usage: tools/sk_ablate.sh
+# instantiation units with parts of the kernel switched off (wrong results, timing only).  usage: tools/experiments/sk_ablate.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/mvlm_amd/csrc

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing of the staging schedule inside a K-chunk (run on the GPU box): loads over the first 1/I of the k-steps, LDS writes
-# over the last 1/W; builds of the c128 / c64 / c96 / c32 instantiation units per (I, W).  usage: tools/stage_sched.sh
+# over the last 1/W; builds of the c128 / c64 / c96 / c32 instantiation units per (I, W).  usage: tools/experiments/stage_sched.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/mvlm_amd/csrc

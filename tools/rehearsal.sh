@@ -5,7 +5,7 @@
 # torch.distributed.run agent that starts them (a run with six ranks was killed by it: "7 processes had the GPU open") - and
 # an N = 8 run is the driver's to launch.  The per-rank shard sizes of the 8-GPU run are kept instead: configs[3] 12 views per
 # rank (60 views in total), configs[4] 16 per rank (80 in total); configs[2] runs its 96 views on 5 ranks (19-20 per rank).
-# usage: tools/r5_rehearsal.sh <tag>   -> gpurun_out/rehearsal_<tag>/<tag>_rehearsal_5ranks_*.json (+ wall seconds of each whole command)
+# usage: tools/rehearsal.sh <tag>   -> gpurun_out/rehearsal_<tag>/<tag>_rehearsal_5ranks_*.json (+ wall seconds of each whole command)
 set -u
 export MVLM_BENCH_LIVE_TRAFFIC=0
 TAG=${1:-r05}
