@@ -24,7 +24,8 @@
  *     beside the launching one: their host work and their device work (a copy / decode stream
  *     of the context's own) happen outside the ctx mutex, under an upload mutex of their own.
  *     mvlm_obj_read / mvlm_mesh_read / mvlm_jpeg_info need no ctx at all
- *     (mvlm_obj_read parses on up to 16 threads of its own; MVLM_OBJ_THREADS overrides).
+ *     (mvlm_obj_read parses on up to 16 threads of its own - the host's cores divided by the number of
+ *     mvlm_obj_read calls in flight; MVLM_OBJ_THREADS overrides).
  */
 #ifndef MVLM_HIP_H
 #define MVLM_HIP_H
@@ -125,6 +126,9 @@ int mvlm_jpeg_decode(mvlm_ctx* ctx, const uint8_t* jpeg_host, size_t jpeg_bytes,
  * out_dev f32[N,256,256,4]: RGB + depth planes in [0,1], already flipped to
  * image orientation (render3d.py:177) and divided by 255 (:191). */
 int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* rot_host, int n_views, float* out_dev);
+/* The device copy of the last render's rotations, f64[n_views,9] (the context's scratch: valid until the next mvlm_render):
+ * mvlm_estimate_lines of the same views takes it as rot_dev, and the table crosses PCIe once per mesh. */
+int mvlm_render_rotations_dev(mvlm_ctx* ctx, const double** rot_dev);
 /* what the RGB planes hold: 0 = unlit white x nearest texel, exactly what the reference renders
  * (utils3d.py:58-64); 1 = build-defined "geometry" shading (flat two-sided head light, grey in all
  * three planes) for models trained on geometry renderings - the reference's renderer has no such

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import threading
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -50,6 +51,7 @@ SIGNATURES = {
     "mvlm_render_check": (C.c_int, [C.c_void_p]),
     "mvlm_render_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_render_get_profile": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, C.c_int]),
+    "mvlm_render_rotations_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mvlm_set_render_shading": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_set_render_subpixel_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_cnn_load": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_int32_p, C.c_int, C.c_int, C.c_int]),
@@ -166,6 +168,20 @@ class Context:
 
     def set_stream(self, stream_ptr: int):
         self.check(self.lib.mvlm_set_stream(self.handle, C.c_void_p(stream_ptr)))
+        self._bound_stream = stream_ptr
+
+    def bind_current_stream(self, torch, dev):
+        """Make torch's current stream on ``dev`` this context's launch stream - unless THIS thread has bound it for a whole
+        step already (``hold_stream``) and nobody has re-bound the context since: asking torch for the stream and telling the
+        library costs ~8 us, and a step of the fused pipeline would do it nine times."""
+        held = getattr(self, "_held_stream", None)
+        if held is not None and held[0] == threading.get_ident() and getattr(self, "_bound_stream", None) == held[1]:
+            return
+        self.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def hold_stream(self, torch, dev):
+        """Context manager: bind torch's current stream once and keep it bound until exit (nested holds are no-ops)."""
+        return _HeldStream(self, torch, dev)
 
     def synchronize(self):
         self.check(self.lib.mvlm_synchronize(self.handle))
@@ -180,6 +196,24 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class _HeldStream:
+    def __init__(self, ctx, torch, dev):
+        self.ctx, self.torch, self.dev, self.mine = ctx, torch, dev, False
+
+    def __enter__(self):
+        if getattr(self.ctx, "_held_stream", None) is None:  # (held by another thread: this one binds call by call)
+            ptr = self.torch.cuda.current_stream(self.dev).cuda_stream
+            self.ctx.set_stream(ptr)
+            self.ctx._held_stream = (threading.get_ident(), ptr)
+            self.mine = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.mine:
+            self.ctx._held_stream = None
+        return False
 
 
 _contexts: dict[int, Context] = {}

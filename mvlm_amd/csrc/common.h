@@ -242,6 +242,7 @@ struct mvlm_ctx {
     int conv_force_variant = -1;            // >= 0: mvlm_conv_bench times exactly this kernel variant
     std::vector<ConvOverride> conv_overrides;  // tools/tune_in_network.py: kernel variant per (shape, kind), before any table
     unsigned long long conv_attr_mask = 0;  // conv variants whose launch attributes are set on this ctx's device
+    size_t raster_keys_clean_cap = 0;  // capacity of the "raster.keys" scratch when it was last left all-EMPTY (0: not known clean)
     int render_subpixel_bits = 8;  // vertex snap 2^-bits pixel (GL_SUBPIXEL_BITS of the OpenGL to match)
     int render_shading = 0;  // 0: unlit nearest-texel RGB (reference), 1: build-defined geometry shading
     int* render_overflow_host = nullptr;  // pinned; written asynchronously by mvlm_render

@@ -9,6 +9,8 @@
 // first use of each (v, vt) pair, negative indices are relative to the elements read so far.
 #include <sched.h>
 
+#include <atomic>
+
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
@@ -268,11 +270,21 @@ long usable_cpus() {
 
 constexpr long MAX_READER_THREADS = 16;
 
-int reader_threads(size_t bytes) {
+// files being parsed right now, process-wide (a folder's ingest runs 1-4 reader threads, each inside mvlm_obj_read): the
+// host's cores are shared among them instead of every call starting a full complement (4 x 16 threads on 16 cores)
+std::atomic<int> g_active_reads{0};
+struct ActiveRead {
+    int n;
+    ActiveRead() : n(++g_active_reads) {}
+    ~ActiveRead() { --g_active_reads; }
+};
+
+int reader_threads(size_t bytes, int active_reads) {
     long want = long(bytes / (256u << 10));  // a thread per 256 KB of text, at most MAX_READER_THREADS
     if (const char* e = getenv("MVLM_OBJ_THREADS")) want = strtol(e, nullptr, 10);
     static const long cpus = usable_cpus();
-    if (!getenv("MVLM_OBJ_THREADS") && want > cpus) want = cpus;
+    const long share = cpus / (active_reads < 1 ? 1 : active_reads);  // this call's part of the cores
+    if (!getenv("MVLM_OBJ_THREADS") && want > share) want = share;
     return int(want < 1 ? 1 : want > MAX_READER_THREADS ? MAX_READER_THREADS : want);
 }
 
@@ -330,7 +342,8 @@ extern "C" int mvlm_obj_read(const char* path, mvlm_obj** out, char* err, int er
     }
     lap("read");
     // ---- cut into chunks right behind a line terminator, parse them side by side
-    const int n_chunks = reader_threads(text.size());
+    const ActiveRead active;
+    const int n_chunks = reader_threads(text.size(), active.n);
     std::vector<Chunk> chunks{size_t(n_chunks)};
     {
         const char* const base = text.data();

@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void tile_kernel(const vert12* __restrict__ tv
                                                    const float* __restrict__ uvs, const uint8_t* __restrict__ tex,
                                                    int tex_w, int tex_h, int n_verts, const int* __restrict__ counts,
                                                    const int* __restrict__ offsets, const int* __restrict__ bins,
-                                                   int cap, const unsigned long long* __restrict__ keys,
-                                                   int shading, int n_views, float* __restrict__ out) {
+                                                   int cap, unsigned long long* __restrict__ keys,
+                                                   int shading, int n_views, const int* __restrict__ overflow,
+                                                   int* __restrict__ overflow_host, float* __restrict__ out) {
     __shared__ rm_tri s_tri[256];  // (valid == 2: small extent, the 24-bit edge functions apply)
     __shared__ int s_id[256];
     int view, tile;
@@ -321,7 +322,16 @@ __global__ __launch_bounds__(256) void tile_kernel(const vert12* __restrict__ tv
     const int n = min(counts[vt], cap - offsets[vt]);
     const int* const list = bins + size_t(view) * cap + offsets[vt];
 
-    uint64_t best = keys[(size_t(view) * RM_SIZE + j) * RM_SIZE + i];  // what the small triangles left
+    unsigned long long* const key_slot = keys + (size_t(view) * RM_SIZE + j) * RM_SIZE + i;
+    uint64_t best = *key_slot;  // what the small triangles left
+    // The key plane is handed back EMPTY: this kernel reads every slot of the rendered views exactly once, so it also clears
+    // what classify dirtied - instead of a 67 MB fill in front of every render (14 us + a launch gap at 128 views)
+    if (best != RM_KEY_EMPTY) *key_slot = RM_KEY_EMPTY;
+    // and the first workgroup carries the overflow flag of the kernels before it to the host's pinned word (no copy node)
+    if (blockIdx.x == 0 && tid == 0) {
+        __atomic_store_n(overflow_host, *overflow, __ATOMIC_RELAXED);
+        __threadfence_system();
+    }
 
     // ---- phase B: every pixel walks the tile's big triangles, set up into LDS a chunk at a time ----
     for (int base = 0; base < n; base += 256) {
@@ -419,7 +429,14 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
     MVLM_CHECK_HIP(ctx, hipMemcpyAsync(rot, rot_host, size_t(n_views) * 9 * sizeof(double), hipMemcpyHostToDevice,
                                        ctx->stream));
     MVLM_CHECK_HIP(ctx, hipMemsetAsync(ctr, 0, ctr_ints * sizeof(int), ctx->stream));
-    MVLM_CHECK_HIP(ctx, hipMemsetAsync(keys, 0xFF, key_bytes, ctx->stream));  // RM_KEY_EMPTY everywhere
+    // The key plane is EMPTY between renders (tile_kernel clears what it reads); it is filled here only when the buffer is new
+    // or a render did not run to its end.  `clean_cap` = the capacity it was last known clean at (a reallocation only grows it).
+    const size_t keys_cap = ctx->scratch["raster.keys"].second;
+    if (ctx->raster_keys_clean_cap != keys_cap)
+        MVLM_CHECK_HIP(ctx, hipMemsetAsync(keys, 0xFF, keys_cap, ctx->stream));  // RM_KEY_EMPTY everywhere
+    ctx->raster_keys_clean_cap = 0;  // (until this call has enqueued its tile kernel)
+    if (!ctx->render_overflow_host)
+        MVLM_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->render_overflow_host), sizeof(int)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->render_profiling) {  // HIP events on the launch stream around the five kernels of this call
         if (ctx->render_event_cursor + 2 > ctx->render_events.size()) ctx->render_events.resize(ctx->render_event_cursor + 2, nullptr);
@@ -441,18 +458,26 @@ extern "C" int mvlm_render(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* r
                        mesh->tris, V, T, n_views, n_big, big_list, offsets, cursors, bins, cap, overflow);
     hipLaunchKernelGGL(tile_kernel, dim3(view_chunk_grid(TILES, n_views)), dim3(256), 0, ctx->stream, tv, mesh->tris,
                        mesh->uvs, mesh->tex, mesh->tex_w, mesh->tex_h, V, counts, offsets, bins, cap, keys,
-                       ctx->render_shading, n_views, out_dev);
+                       ctx->render_shading, n_views, overflow, ctx->render_overflow_host, out_dev);
     MVLM_CHECK_HIP(ctx, hipGetLastError());
+    ctx->raster_keys_clean_cap = keys_cap;
     if (e1) {
         MVLM_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));
         ctx->render_prof.push_back({n_views, V, T, e0, e1});
     }
-    // the overflow flag travels to pinned host memory without stalling the stream; it is
-    // examined by mvlm_render_check (after the caller's own synchronisation point)
-    if (!ctx->render_overflow_host)
-        MVLM_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->render_overflow_host), sizeof(int)));
-    MVLM_CHECK_HIP(ctx, hipMemcpyAsync(ctx->render_overflow_host, overflow, sizeof(int), hipMemcpyDeviceToHost,
-                                       ctx->stream));
+    // (the overflow flag has travelled to pinned host memory inside the tile kernel; mvlm_render_check examines it after the
+    // caller's own synchronisation point)
+    return 0;
+}
+
+// The rotations of the last mvlm_render on this context, f64[n_views, 9] on the device (its scratch: valid until the next
+// render): the estimator's rays of the same views need the same table (estimator3d.py:57) and read it from here.
+extern "C" int mvlm_render_rotations_dev(mvlm_ctx* ctx, const double** rot_dev) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MVLM_REQUIRE(ctx, rot_dev, "render_rotations_dev: null pointer");
+    const auto it = ctx->scratch.find("raster.rot");
+    *rot_dev = it == ctx->scratch.end() ? nullptr : static_cast<const double*>(it->second.first);
+    MVLM_REQUIRE(ctx, *rot_dev, "render_rotations_dev: nothing has been rendered on this context");
     return 0;
 }
 

@@ -171,6 +171,16 @@ class Pipeline(abc.ABC):
             self._buffers[name] = buf
         return buf
 
+    def _pinned_bytes(self, name: str, n_bytes: int):
+        """(pinned uint8 host tensor of exactly this size, its numpy view) that live as long as the pipeline."""
+        import torch
+
+        ent = self._buffers.get(name)
+        if ent is None or ent[0].numel() != n_bytes:
+            t = torch.empty(n_bytes, dtype=torch.uint8).pin_memory()
+            ent = self._buffers[name] = (t, t.numpy())
+        return ent
+
     def _buffer_bytes(self, name: str, n_bytes: int):
         """A uint8 device buffer of at least this size that lives as long as the pipeline (8-byte aligned slices)."""
         import torch
@@ -278,14 +288,21 @@ class Pipeline(abc.ABC):
 
         rot = view_rotations(transform_stack)  # once per call: renderer and estimator share it
         tm = self._timer
-        # Everything the host has to prepare goes first, while the stream is empty: a host-to-device copy from
-        # ordinary memory waits for the work enqueued before it, so uploads issued behind the network would stall
-        # the host until the network has finished and leave the GPU idle while the host catches up.
+        dev_t = torch.device("cuda", self.device)
+        # this call owns the renderer's / estimator's context until it returns: the launch stream is bound once
+        with r3.ctx.hold_stream(torch, dev_t), e3.ctx.hold_stream(torch, dev_t):
+            return self._predict_mesh_device_held(mesh, transform_stack, rot, r3, p2, e3, tm, dev_t, n_total, sharded, rank, lo, hi)
+
+    def _predict_mesh_device_held(self, mesh, transform_stack, rot, r3, p2, e3, tm, dev_t, n_total, sharded, rank, lo, hi):
+        import torch
+
+        # What the GPU waits for first is the render: single-process, it is enqueued before anything else the host has to
+        # prepare (the rotations' second upload, the result buffers, the RANSAC draws: all of that then happens while the
+        # rasteriser runs - at 0.5 ms per step, configs[4], the host's serial part is what the step time is made of).
+        # Sharded, the draws come out of a collective, which must not queue up behind this step's network: they go first.
         draws_fn = None
         if sharded:
             # one RNG stream for the job: rank 0 draws (global numpy RNG, as the reference) and broadcasts the table
-            dev_t = torch.device("cuda", self.device)
-
             def draws_fn(counts, keep_on_device=False):
                 draws = e3.draw_ransac_indices(counts) if rank == 0 else None
                 return parallel.broadcast_int32(draws, (len(counts), 8), dev_t, keep_on_device=keep_on_device)
@@ -293,14 +310,7 @@ class Pipeline(abc.ABC):
             draws_fn.device_result = True  # plan_draws may ask for the collective's device tensor (RCCL)
 
         nl_all = p2.get_lm_count()
-        # sharded: the draws come out of a collective, which must not queue up behind this step's network
         plan = e3.plan_draws(nl_all, n_total, draws_fn) if sharded else None
-        rot_dev = e3.upload_rotations(rot)
-        # landmarks f64[NL,3] | error f64[NL] | survivor counts i32[NL] in ONE buffer: one device-to-host copy per mesh
-        pack = self._buffer_bytes("result", nl_all * (24 + 8 + 4))
-        snap_view = pack[: nl_all * 24].view(torch.float64).view(nl_all, 3)
-        err_view = pack[nl_all * 24: nl_all * 32].view(torch.float64)
-        count_view = pack[nl_all * 32: nl_all * 36].view(torch.int32)
         with tm.stage("render"):
             # one image stack / maxima buffer per view count, reused from call to call: stable addresses let the
             # predictor replay its captured launch graph instead of re-enqueueing ~160 kernels per mesh
@@ -310,6 +320,18 @@ class Pipeline(abc.ABC):
                                           out=self._buffer("images", (hi - lo, 256, 256, 4)))
             if self.verbose:
                 torch.cuda.synchronize()
+        if images is not None and hi - lo == n_total and r3.ctx is e3.ctx:
+            rot_dev = r3.rotations_device()   # all views rendered here: the rays read the rasteriser's own device copy
+        else:
+            # (enqueued behind the render on the same stream, through pinned staging: the host does not wait)
+            rot_dev = e3.upload_rotations_async(rot)
+        # landmarks f64[NL,3] | error f64[NL] | survivor counts i32[NL] in ONE buffer: one device-to-host copy per mesh,
+        # into pinned memory, enqueued right behind the last kernel
+        pack = self._buffer_bytes("result", nl_all * (24 + 8 + 4))
+        pack_host, pack_np = self._pinned_bytes("result_host", int(pack.numel()))
+        snap_view = pack[: nl_all * 24].view(torch.float64).view(nl_all, 3)
+        err_view = pack[nl_all * 24: nl_all * 32].view(torch.float64)
+        count_view = pack[nl_all * 32: nl_all * 36].view(torch.int32)
         if self.render_image_stack and images is not None:
             self.visualize_image_stack(images.cpu().numpy(), mesh.path or Path("mesh.obj"), first_index=lo)
 
@@ -338,7 +360,7 @@ class Pipeline(abc.ABC):
             keep = np.nonzero(valid)[0]
             maxima = maxima.index_select(1, torch.from_numpy(keep).to(maxima.device)).contiguous()
             transform_stack = transform_stack[keep]
-            rot_dev = e3.upload_rotations(rot[keep])
+            rot_dev = e3.upload_rotations_async(rot[keep])
             n_total = int(len(keep))
             if plan is not None:  # sharded: the draws planned for all views are void - plan again for the views that remain
                 np.random.set_state(plan["rng_state"])
@@ -361,14 +383,18 @@ class Pipeline(abc.ABC):
         with tm.stage("project"):
             # the snap is enqueued before anything is fetched: one wait and one copy per mesh, at the end
             e3.project_device(mesh, out, out=snap_view)
-            host = pack.cpu().numpy()
+            stream = torch.cuda.current_stream(dev_t)
+            pack_host.copy_(pack, non_blocking=True)
+            stream.synchronize()
+            host = pack_np
             if verify(counts=host[nl_all * 32: nl_all * 36].view(np.int32)):
                 # the RANSAC draws had to be repeated for other survivor counts (tied / NaN scores, absolute mode)
                 e3.project_device(mesh, out, out=snap_view)
-                host = pack.cpu().numpy()
+                pack_host.copy_(pack, non_blocking=True)
+                stream.synchronize()
             landmarks = host[: nl_all * 24].view(np.float64).reshape(nl_all, 3).copy()
             error = e3.mean_error(host[nl_all * 24: nl_all * 32].view(np.float64))
-            r3.check()  # deferred renderer status (the .cpu() above already synchronised)
+            r3.check()  # deferred renderer status (the stream has been waited for above)
         asked16 = getattr(p2, "configured_precision", getattr(p2, "precision", None)) == "fast16"
         if asked16:
             # an activation beyond fp16's range somewhere in the network (the kernel raised the context's flag; the maxima of

@@ -33,20 +33,46 @@ class HipEstimator3D:
         self.ctx = _lib.get_context(device)
         self._upload_stream = None
         self._draw_bufs: dict = {}
+        self._rot_bufs: dict = {}
+        self._rot_next = 0
 
     # ---- helpers ----------------------------------------------------------------------
     def _torch(self):
         import torch
 
         dev = torch.device("cuda", self.ctx.device)
-        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.bind_current_stream(torch, dev)
         return torch, dev
 
     def upload_rotations(self, rot: np.ndarray):
         """[N,9] float64 view rotations -> device tensor.  A host-to-device copy from ordinary memory waits for the
         work already enqueued on the stream, so the pipeline does this before it enqueues the step's GPU work."""
         torch, dev = self._torch()
-        return torch.from_numpy(np.ascontiguousarray(rot, dtype=np.float64)).to(dev)
+        rot = np.ascontiguousarray(rot, dtype=np.float64)
+        if not rot.flags.writeable:  # (view_rotations hands out its memoised tables read-only; torch wants to own writable memory)
+            rot = rot.copy()
+        return torch.from_numpy(rot).to(dev)
+
+    def upload_rotations_async(self, rot: np.ndarray):
+        """The same through pinned staging and a copy ENQUEUED on the current stream: the host does not wait for the work
+        already there (the fused pipeline calls this right behind the render it has just enqueued; the rays come after the
+        render anyway).  Two staging slots, each guarded by the event of its last copy."""
+        torch, dev = self._torch()
+        rot = np.ascontiguousarray(rot, dtype=np.float64)
+        n = int(rot.shape[0])
+        slots = self._rot_bufs.get(n)
+        if slots is None:
+            slots = self._rot_bufs[n] = [[torch.empty((n, 9), dtype=torch.float64).pin_memory(),
+                                          torch.empty((n, 9), dtype=torch.float64, device=dev), torch.cuda.Event(), None] for _ in range(2)]
+            for sl in slots:
+                sl[3] = sl[0].numpy()
+        self._rot_next ^= 1
+        pinned, dev_buf, event, view = slots[self._rot_next]
+        event.synchronize()  # (long done: a step ends with a wait for its results)
+        view[...] = rot
+        dev_buf.copy_(pinned, non_blocking=True)
+        event.record()
+        return dev_buf
 
     def lines_device(self, landmarks_dev, transform_stack, image_size: int = 256, rot: np.ndarray | None = None,
                      rot_dev=None):
@@ -244,7 +270,7 @@ class HipEstimator3D:
         n = int(e.numel() // 3)
         if n:
             handle = upload_mesh(self.ctx, mesh)
-            self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            self.ctx.bind_current_stream(torch, dev)
             self.ctx.check(self.ctx.lib.mvlm_clip_rays_to_mesh(
                 self.ctx.handle, handle, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), n, C.c_void_p(out.data_ptr()),
                 C.c_void_p(hit.data_ptr())))

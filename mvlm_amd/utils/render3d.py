@@ -42,6 +42,24 @@ def view_rotations(transform_stack: np.ndarray) -> np.ndarray:
     n = t.shape[0]
     if n == 0:
         return np.zeros((0, 9))
+    # the fixed 8-view table (render3d.py:94-111) is the same for every scan, and a caller that repeats a pose table gets the
+    # same answer: the last few tables are kept (read-only), keyed by the angles' bytes
+    key = (t.dtype.str, n, t[:, :3].tobytes())
+    hit = _ROTATION_MEMO.get(key)
+    if hit is not None:
+        return hit
+    out = _view_rotations_uncached(t, n)
+    out.setflags(write=False)
+    if len(_ROTATION_MEMO) >= 8:
+        _ROTATION_MEMO.pop(next(iter(_ROTATION_MEMO)))
+    _ROTATION_MEMO[key] = out
+    return out
+
+
+_ROTATION_MEMO: dict = {}
+
+
+def _view_rotations_uncached(t: np.ndarray, n: int) -> np.ndarray:
     r = np.deg2rad(t[:, :3].astype(np.float64))
     c, s = np.cos(r), np.sin(r)
     mx, my, mz = np.zeros((n, 3, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3, 3))
@@ -110,6 +128,16 @@ def upload_mesh(ctx: "_lib.Context", mesh: Mesh) -> C.c_void_p:
 
     mesh._device[key] = (handle, _Owner(ctx, handle))
     return handle
+
+
+class _DevicePointer:
+    """A borrowed device address with the one method the C-ABI wrappers ask of a tensor."""
+
+    def __init__(self, ptr: int):
+        self._ptr = int(ptr)
+
+    def data_ptr(self) -> int:
+        return self._ptr
 
 
 class _TextureAhead:
@@ -209,12 +237,23 @@ class HipRenderer3D:
             raise ValueError("render_device: out must be a contiguous float32 [N,256,256,4] tensor on the renderer's GPU")
         rot = np.ascontiguousarray(view_rotations(transform_stack) if rot is None else rot, dtype=np.float64)
         handle = upload_mesh(self.ctx, mesh)
-        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        self.ctx.check(self.ctx.lib.mvlm_set_render_shading(self.ctx.handle, 1 if self.shading == "geometry" else 0))
-        self.ctx.check(self.ctx.lib.mvlm_set_render_subpixel_bits(self.ctx.handle, self.subpixel_bits))
+        self.ctx.bind_current_stream(torch, dev)
+        mode = (1 if self.shading == "geometry" else 0, self.subpixel_bits)
+        if getattr(self.ctx, "_render_mode", None) != mode:  # (renderers of one GPU share the context)
+            self.ctx.check(self.ctx.lib.mvlm_set_render_shading(self.ctx.handle, mode[0]))
+            self.ctx.check(self.ctx.lib.mvlm_set_render_subpixel_bits(self.ctx.handle, mode[1]))
+            self.ctx._render_mode = mode
         self.ctx.check(self.ctx.lib.mvlm_render(self.ctx.handle, handle, _lib.as_ptr(rot, C.c_double), n,
                                                 C.c_void_p(out.data_ptr())))
         return out
+
+    def rotations_device(self):
+        """The last render's rotation table where the rasteriser keeps it on the device (f64[N,9]; valid until this context's
+        next render): an object with ``data_ptr()`` that ``HipEstimator3D.lines_device(rot_dev=...)`` takes - the rays of the
+        same views need the same matrices (estimator3d.py:57), so the table crosses PCIe once per mesh."""
+        p = C.c_void_p()
+        self.ctx.check(self.ctx.lib.mvlm_render_rotations_dev(self.ctx.handle, C.byref(p)))
+        return _DevicePointer(p.value)
 
     def check(self):
         """Wait for the stream and raise if an enqueued render failed."""
@@ -271,12 +310,18 @@ class HipRenderer3D:
         # while this one parses the geometry (2.7 ms): the scan is ready when the slower of the two is.
         import threading
 
-        box: list = [None, None, None]  # bytes, device texture, exception
+        box: list = [None, None, None, None]  # bytes, device texture, exception, host-decoded pixels (device refused)
 
         def texture_job():
             try:
                 box[0] = jpg.read_bytes()
                 box[1] = decode_texture_ahead(self.ctx, box[0])
+                if box[1] is None:
+                    # not a JPEG the device takes (progressive ones are common among exported textures): libjpeg on the host,
+                    # HERE, beside the geometry parse - not afterwards on the caller's thread inside upload_mesh
+                    from .mesh_io import decode_texture_bytes
+
+                    box[3] = decode_texture_bytes(box[0])
             except Exception as e:  # noqa: BLE001 - "if we cannot load the texture, we just ignore it" (utils3d.py:35-36) ...
                 box[2] = e        # ... but a failing GPU call is not a texture problem: raised below
 
@@ -290,7 +335,13 @@ class HipRenderer3D:
             raise box[2]
         if mesh.uvs is not None and box[0] is not None:  # utils3d.py:26: only with tcoords
             mesh.texture_jpeg = box[0]
-            mesh._texture_ahead = box[1]  # None: not a JPEG the device takes - the upload / Mesh.texture decode on the host
+            mesh._texture_ahead = box[1]
+            if box[1] is None:
+                # decoded on the host by the texture thread (or not decodable at all: ignored, utils3d.py:35-36): the upload
+                # goes straight to mvlm_mesh_upload, without a second look at the header
+                mesh._texture = box[3]
+                if box[3] is None:
+                    mesh.texture_jpeg = None
         return aligned(mesh, self.pre_align)
 
     def multiview_render_device(self, file_or_mesh, transformation_stack=None):

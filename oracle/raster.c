@@ -5,15 +5,21 @@
  * src/mvlm/utils/render3d.py:114-177 + :191 and src/mvlm/utils/utils3d.py:26-64.
  * The arithmetic itself lives in the third-party `vtk` package (absent here), so
  * this file follows the *specification* written down in DESIGN.md ("Renderer
- * contract") rather than executable reference code - PARITY UNPINNED at pixel level:
+ * contract") rather than executable reference code - PARITY UNPINNED against VTK at pixel
+ * level.  What VTK asks of OpenGL, however, was drawn by a real OpenGL (SwiftShader GLES 3.0,
+ * tools/make_gl_golden.py -> tests/golden/gl_raster.npz) and this file is held against that
+ * (tests/test_gl_contract.py): fill rule, pixel centres, depth mapping and byte conversion,
+ * LEQUAL, clip planes, texel addressing and flip below are the ones that GL shows; what GL
+ * leaves to the implementation (sub-pixel bits, guard band) is listed in DESIGN.md section 5:
  *   - per pose M = Ry*Rx*Rz (render3d.py:140-144) applied in double, points kept
  *     as float (vtkTransformPolyDataFilter on float points),
  *   - orthographic camera at z=+500 looking down -z, parallel scale 150, 256x256
  *     window (render3d.py:50, :150-152): window x = (x+150)*256/300, same for y,
  *   - depth = (500 - z)/1500 for the (0,1500) clip range (render3d.py:136),
- *   - vertices snapped to 1/256 pixel, pixel centres at (i+0.5, j+0.5), every pixel
- *     on a shared edge owned by exactly one triangle, depth test LEQUAL in draw
- *     order (VTK default) i.e. a later triangle replaces an equal depth,
+ *   - vertices snapped to 1/256 pixel (2^-bits: oracle_render_bits), pixel centres at
+ *     (i+0.5, j+0.5), a centre on a shared edge owned by the triangle whose left / bottom
+ *     edge it is, attributes interpolated as the plane through the first vertex, depth
+ *     test LEQUAL in draw order (VTK default) i.e. a later triangle replaces an equal depth,
  *   - unlit white material modulated by the nearest texel (utils3d.py:32, :61-64),
  *     white background (render3d.py:54),
  *   - depth plane = (256 - trunc(255*z)) mod 256 (vtkImageShiftScale scale -255 to

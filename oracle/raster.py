@@ -1,5 +1,6 @@
 """Oracle: CPU multi-view renderer, ctypes wrapper around oracle/raster.c.
-TEST INFRASTRUCTURE - see oracle/__init__.py.  PARITY UNPINNED against VTK (absent)."""
+TEST INFRASTRUCTURE - see oracle/__init__.py.  PARITY UNPINNED against VTK (absent); held against a real OpenGL's
+rendering of the reference's GL work (tests/golden/gl_raster.npz, tests/test_gl_contract.py)."""
 from __future__ import annotations
 
 import ctypes as C

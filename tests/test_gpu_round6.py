@@ -1,0 +1,78 @@
+"""Round 6, -m gpu: what changed in the render / fusion step for configs[4] (0.55 -> 0.44 ms per 128-view mesh) keeps every result."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _face(grid, seed=1, tex=64):
+    from mvlm_amd.utils.synthetic import face_like_mesh
+
+    return face_like_mesh(grid=grid, tex_size=tex, seed=seed)
+
+
+def test_key_plane_is_left_clean_between_renders():
+    """The tile kernel hands the depth-key plane back EMPTY instead of a fill in front of every render: a scene that covers
+    much, then one that covers little, more views, fewer views, another mesh - each bit-equal to the oracle, which starts from
+    a fresh z-buffer every time."""
+    from mvlm_amd.utils import HipRenderer3D, Mesh
+    from oracle import raster
+
+    big = Mesh(np.array([[-400, -400, 0], [400, -400, 0], [0, 600, 0]], np.float32), np.array([[0, 1, 2]], np.int32))
+    small = Mesh(np.array([[-10, -10, 50], [10, -10, 50], [0, 12, 50]], np.float32), np.array([[0, 1, 2]], np.int32))
+    face = _face(60)
+    r = HipRenderer3D(n_views=8, verbose=False)
+    rs = np.random.RandomState(5)
+    for mesh, n in ((big, 8), (small, 8), (face, 24), (small, 3), (face, 8), (big, 40), (small, 40)):
+        poses = np.stack([rs.randint(-40, 40, n), rs.randint(-80, 80, n), rs.randint(-20, 20, n)], 1).astype(np.float64)
+        got = r.render_device(mesh, poses).cpu().numpy()
+        r.check()
+        want = raster.multiview_render(mesh.verts, mesh.tris, mesh.uvs, mesh.texture, poses)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_rays_from_the_rasterisers_own_rotation_table():
+    """lines_device with the table the last render left on the device == with a table uploaded for it (bit for bit), and the
+    borrowed table follows the next render."""
+    from mvlm_amd.utils import HipEstimator3D, HipRenderer3D
+
+    r = HipRenderer3D(n_views=96, verbose=False)
+    e = HipEstimator3D(verbose=False)
+    assert r.ctx is e.ctx
+    mesh = _face(30)
+    rs = np.random.RandomState(2)
+    for seed in (4, 9):
+        np.random.seed(seed)
+        poses = r.generate_3d_transformations()
+        maxima = torch.from_numpy(rs.uniform(0, 255, (73, 96, 3)).astype(np.float32)).cuda()
+        r.render_device(mesh, poses)
+        s1, e1 = e.lines_device(maxima, poses, 256, rot_dev=r.rotations_device())
+        s2, e2 = e.lines_device(maxima, poses, 256)
+        assert torch.equal(s1, s2) and torch.equal(e1, e2)
+        assert float(s1.abs().max()) > 100.0
+
+
+def test_fused_step_equals_the_slot_protocol_after_the_reordering(tmp_path):
+    """predict_mesh_device (render first, rotations borrowed from the rasteriser, results through pinned memory, stream bound
+    once) against the reference's slot-by-slot protocol on host arrays, twice in a row (buffers and staging slots reused)."""
+    from mvlm_amd import pipeline
+    from mvlm_amd.utils.mesh_io import load_obj
+    from mvlm_amd.utils.synthetic import write_face_like_obj
+
+    obj = write_face_like_obj(tmp_path / "f.obj", grid=41, tex_size=64, seed=2)
+    pipe = pipeline.create_pipeline("dtu3d", n_views=12, weights="synthetic:5", verbose=False)
+    mesh = load_obj(obj)
+    for seed in (3, 4):
+        np.random.seed(seed)
+        poses = pipe.renderer_3d.generate_3d_transformations()
+        state = np.random.get_state()
+        fused, err = pipe.predict_mesh_device(mesh, poses)
+        np.random.set_state(state)
+        images = pipe.renderer_3d.render_device(mesh, poses).cpu().numpy()
+        lms, valid = pipe.predictor_2d.predict_landmarks_from_images(images)
+        starts, ends = pipe.estimator_3d.estimate_landmark_lines(images, lms, poses)
+        raw, err2 = pipe.estimator_3d.estimate_landmarks_from_lines(lms, starts, ends)
+        slots = pipe.estimator_3d.project_landmarks_to_surface(mesh, raw)
+        np.testing.assert_array_equal(fused, slots)
+        assert err == err2
