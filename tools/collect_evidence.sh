@@ -30,6 +30,9 @@ timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe fast 
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 64 224 dtu3d fast RGB > $OUT/${TAG}_fast_vs_oracle_dtu3d_rgb_64views.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe fast16 RGB+depth > $OUT/${TAG}_fast16_vs_oracle_bu3dfe_rgbd_96views.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 64 224 dtu3d fast16 RGB > $OUT/${TAG}_fast16_vs_oracle_dtu3d_rgb_64views.txt 2>&1 || exit 1
+echo "== the renderer contract against a real OpenGL's rendering (tests/golden/gl_raster.npz), the reference's own textures" ; date
+timeout -k 10 300 python3 tests/reports/gl_contract_report.py > $OUT/${TAG}_gl_contract.txt 2>&1 || exit 1
+timeout -k 10 300 python3 -m pytest tests/test_real_textures.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep "synchronisation rounds\|passed\|failed" > $OUT/${TAG}_real_textures.txt || exit 1
 echo "== moment selection (fused) beside simple" ; date
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_96views.json 2> /dev/null || exit 1
 timeout -k 10 300 python3 bench.py --config dtu3d-geomdepth-96 --views-total 12 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_12views.json 2> /dev/null || exit 1
@@ -75,5 +78,7 @@ timeout -k 10 300 bash tools/raster_trace.sh raster_$TAG > /dev/null 2>&1 || exi
 (cat $ROOT/gpurun_out/raster_$TAG/bench.txt; echo; cat $ROOT/gpurun_out/raster_$TAG/kernels.txt) > $OUT/${TAG}_raster_trace.txt
 timeout -k 10 300 bash tools/mediapipe_kernel_stats.sh > /dev/null 2>&1 || exit 1
 cut -c1-260 $ROOT/gpurun_out/mp478/kernel_stats.csv | head -24 > $OUT/${TAG}_mediapipe_kernel_stats.csv
+timeout -k 10 300 bash tools/mediapipe_timeline.sh _$TAG > /dev/null 2>&1 || exit 1
+cp $ROOT/gpurun_out/mp_tl_$TAG/last_steps.txt $OUT/${TAG}_mediapipe_timeline.txt
 fi
 date; ls -la $OUT

@@ -17,7 +17,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mvlm_amd import _lib  # noqa: E402
 
-CASES = [  # name, cin, cout, size, k, batch, pre-BN, residual, bias+post-BN
+CASES = [  # name, cin, cout, size, k, batch, pre-BN, residual, bias+post-BN  (MVLM_PHASE_BATCH overrides the batch)
     ("block conv1  256->128 @128 (c128)", 256, 128, 128, 3, 64, True, True, False),
     ("conv5        256->256 @128 (c128)", 256, 256, 128, 3, 64, False, False, True),
     ("block conv2  128-> 64 @128 (c64)", 128, 64, 128, 3, 64, True, True, False),
@@ -56,6 +56,7 @@ def main():
     f = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
     print(f"{'layer':40s} {'ms':>7s} {'TFLOP/s':>8s} | per workgroup, wave 0: prologue / K loop / epilogue (cycles, share)")
     for name, cin, cout, size, k, batch, pre, res, post in CASES:
+        batch = int(os.environ.get("MVLM_PHASE_BATCH", batch))
         x = torch.randn(batch, cin, size, size, device="cuda")
         y = torch.empty(batch, cout, size, size, device="cuda")
         r = torch.randn(batch, cout, size, size, device="cuda") if res else None

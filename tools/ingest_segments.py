@@ -57,3 +57,28 @@ def load_ahead_and_upload():
     m = pipe.renderer_3d.load_mesh(obj); upload_mesh(ctx, m); torch.cuda.synchronize()
 print(f"HipRenderer3D.load_mesh + upload until done (JPEG decoded on the device by a second thread beside the OBJ parse): {best(load_ahead_and_upload):.2f} ms")
 print("texture file:", obj.with_suffix('.jpg').stat().st_size, "bytes")
+# ---- the same scan with one of the REFERENCE'S OWN scanner textures (assets/Normal-Emotion/angry_01.jpg, committed as data:
+# 3546 x 2282, another encoder's tables, 2.2 MB, no restart markers; utils3d.py:26-36 is its consumer) ----------------------
+real = Path(__file__).resolve().parents[1] / "tests" / "golden" / "jpeg" / "real" / "angry_01.jpg"
+if real.exists():
+    import shutil
+    obj2 = d / "real" / "face.obj"
+    obj2.parent.mkdir()
+    shutil.copyfile(obj, obj2)
+    shutil.copyfile(real, obj2.with_suffix(".jpg"))
+    rgb = pipeline.create_pipeline("bu3dfe", n_views=96, weights="synthetic:0", image_mode="RGB+depth", verbose=False)
+    for _ in range(3):
+        rgb.predict_one_file(obj2)
+    print(f"real texture ({real.name}, {real.stat().st_size} bytes): libjpeg on one core {best(lambda: mesh_io._read_texture(obj2.with_suffix('.jpg')), 5):.2f} ms")
+    def load_up2(mode):
+        m = load_obj(obj2, decode=mode); upload_mesh(ctx, m); torch.cuda.synchronize()
+    print(f"real texture: load_obj + upload until done, JPEG on the host {best(lambda: load_up2('host'), 5):.2f} ms, on the device {best(lambda: load_up2('device'), 5):.2f} ms")
+    def ahead2():
+        m = rgb.renderer_3d.load_mesh(obj2); upload_mesh(ctx, m); torch.cuda.synchronize()
+    print(f"real texture: HipRenderer3D.load_mesh + upload until done (device decode beside the OBJ parse): {best(ahead2, 5):.2f} ms")
+    for mode in ("device", "host"):
+        rgb.renderer_3d.texture_decode = mode
+        ts = []
+        for _ in range(5):
+            t = T(); rgb.predict_one_file(obj2); ts.append(T() - t)
+        print(f"real texture: predict_one_file from disk, 96 views RGB+depth, JPEG on the {mode}: {1e3 * min(ts):.2f} ms = {96 / min(ts):.1f} views/s with ingest")
