@@ -81,8 +81,6 @@ struct Cfg {
     static constexpr bool HAS_IN2 = !SPLITK && COUT_T == 128 && TW == 32 && TRI == 8 && NIMG == 1 && KS == 3 && CK == 4;
     // variants that also exist as a two-problem launch (conv_pair_kernel): the tiles of the residual blocks' 3x3 convolutions
     static constexpr bool PAIRABLE = KS == 3 && COUT_T % 32 == 0 && COUT_T != 96 && !(SPLITK && PIX_T != 32);
-    // round-6 experiment (MVLM_CONV_PERSIST): the 64- and 128-channel 8x32-pixel tiles also exist as persistent workgroups
-    static constexpr bool PERSISTABLE = !SPLITK && KS == 3 && TW == 32 && TRI == 8 && NIMG == 1 && (COUT_T == 64 || COUT_T == 128);
     static_assert(SPLITK ? ((PIX_T == 32 || PIX_T == 64) && COUT_T == 32 && CK % 8 == 0) : (PIX_T % 128 == 0),
                   "pixel tile must split into 4 waves x 32-pixel MFMA columns (or be one or two columns for split-K)");
     static_assert(!TAIL4 || PIX_T == 256, "the 4-row strip gives every lane of a wave one pixel: 64 pixels per wave");
@@ -310,7 +308,7 @@ __device__ __forceinline__ void compute_chunk(const ConvArgs& a, const float* st
 // of the same tile configuration in one grid.
 template <class C, bool AMAX, bool IN2 = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_x, const int tiles_y, const int cout_tiles,
-                                          const int bid, const int nblk, const bool ablate_first_stage = false) {
+                                          const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -486,18 +484,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a_in, const int tiles_
             }
         }
     }
-    // (ablate_first_stage: timing experiment of the persistent form only - a tile after a workgroup's first one starts without
-    // staging its first chunk, i.e. as if a perfect prefetch had hidden the prologue's memory round trip; wrong results)
-    if (!ablate_first_stage) {
-        static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true, IN2>(a, cb0, tid, HWin, sbn, goff, woff_g, regs, smem, goff2); });
-        if (a.pre_scale != nullptr) {
-            for (int i = tid; i < a.cin_pad; i += 256) {
-                sbn[i] = a.pre_scale[i];
-                sbn[C::BN_MAXC + i] = a.pre_shift[i];
-            }
+    static_for<0, T_TOT>([&](auto tc) { issue_item<C, decltype(tc)::value, true, IN2>(a, cb0, tid, HWin, sbn, goff, woff_g, regs, smem, goff2); });
+    if (a.pre_scale != nullptr) {
+        for (int i = tid; i < a.cin_pad; i += 256) {
+            sbn[i] = a.pre_scale[i];
+            sbn[C::BN_MAXC + i] = a.pre_shift[i];
         }
-        static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value, IN2>(a, cb0, tid, smem, goff, regs); });
     }
+    static_for<0, T_TOT>([&](auto tc) { write_item<C, decltype(tc)::value, IN2>(a, cb0, tid, smem, goff, regs); });
     __syncthreads();
 
 #if defined(MVLM_CONV_TIMING)
@@ -1245,19 +1239,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_mfma_kernel(co
     conv_tile<C, AMAX, IN2>(a_in, tiles_x, tiles_y, cout_tiles, int(blockIdx.x), int(gridDim.x));
 }
 
-// Round-6 experiment (review item 7), behind MVLM_CONV_PERSIST=<workgroups per CU>: persistent workgroups - a grid of
-// 256 CUs x that many, every workgroup walks tiles bid, bid + grid, ... (grid is a multiple of 8: a tile keeps the XCD its
-// id names, so conv_tile's XCD-aware order holds).  What it removes is the workgroup's launch and retirement per tile;
-// the tile program itself is conv_tile unchanged, so results are bit for bit the plain launch's.
-template <class C>
-__global__ __launch_bounds__(256, C::MIN_BLOCKS_PER_CU) void conv_persist_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
-                                                                                 const int cout_tiles, const int nblk, const int ablate) {
-    for (int bid = int(blockIdx.x); bid < nblk; bid += int(gridDim.x)) {
-        conv_tile<C, false>(a, tiles_x, tiles_y, cout_tiles, bid, nblk, ablate != 0 && bid != int(blockIdx.x));
-        __syncthreads();  // the stages and the BatchNorm table are rewritten by the next tile's prologue
-    }
-}
-
 // Two independent convolutions in ONE grid (same tile configuration; e.g. conv j of a hourglass level's skip block and
 // conv j of the block that starts the next lower level - paulsenpredictor.py:301-361, up1 = rb(x) beside low1 =
 // rb(pool(x))): workgroups [0, nblk[0]) belong to problem 0, [nblk0_pad, gridDim.x) to problem 1 (nblk0_pad = nblk[0] rounded
@@ -1385,23 +1366,6 @@ int launch_variant(mvlm_ctx* ctx, const ConvArgs& a_in, int variant_id) {
             return ctx->fail("conv: this kernel variant has no second-input form");
         }
     } else {
-        if constexpr (C::PERSISTABLE) {
-            static const int persist = [] { const char* e = getenv("MVLM_CONV_PERSIST"); return e ? atoi(e) : 0; }();
-            const int per_cu = persist < C::MIN_BLOCKS_PER_CU ? persist : C::MIN_BLOCKS_PER_CU;  // what a CU holds of this tile
-            if (persist > 0 && a.kparts <= 1 && g.nblk > 256 * per_cu) {
-                static bool attr_set = false;
-                if (!attr_set) {
-                    MVLM_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_persist_kernel<C>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES)));
-                    attr_set = true;
-                }
-                static const int ablate = getenv("MVLM_CONV_PERSIST_ABLATE_PROLOGUE") ? 1 : 0;  // timing only, wrong results
-                hipLaunchKernelGGL((conv_persist_kernel<C>), dim3(256u * unsigned(per_cu)), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
-                                   g.tiles_x, g.tiles_y, g.cout_tiles, g.nblk, ablate);
-                MVLM_CHECK_HIP(ctx, hipGetLastError());
-                return 0;
-            }
-        }
         hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)g.nblk), dim3(256), C::LDS_BYTES, ctx->cur_stream(), a,
                            g.tiles_x, g.tiles_y, g.cout_tiles);
     }

@@ -1,4 +1,6 @@
 # Round 6, review item 7: the 64-channel (and 128-channel) 8x32 tiles as persistent workgroups (MVLM_CONV_PERSIST), against
+# NOTE: the kernel form this script switches on (MVLM_CONV_PERSIST, MVLM_CONV_PERSIST_ABLATE_PROLOGUE) was an experiment and has been removed
+# again; it is in commit b6a0294 (mvlm_amd/csrc/conv_kernel.h).  Result: profiles/r06_persistent_tile_experiment.txt.
 # the plain launch: single layers on idle data (A/B only), the whole 96-view step on real data, and the timing-only upper
 # bound "as if a perfect prefetch hid every later tile's first-chunk round trip" (MVLM_CONV_PERSIST_ABLATE_PROLOGUE: wrong results).
 set -u
