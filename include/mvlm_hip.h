@@ -297,6 +297,21 @@ int mvlm_project_to_surface(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* 
 int mvlm_clip_rays_to_mesh(mvlm_ctx* ctx, const mvlm_mesh* mesh, const double* starts_dev, const double* ends_dev,
                            int n_rays, double* new_ends_dev, uint8_t* hit_dev);
 
+/* ---- multi-GPU: the one exchange of the sharded path (the reference's counterpart is the dormant
+ * nn.DataParallel of paulsenpredictor.py:100-105) ---------------------------------------------------------------------
+ * Views are sharded contiguously over `world` ranks (rank r holds views [r*base + min(r, rem), ...), sizes differing by at most
+ * one: mvlm_amd/parallel.py shard_range); every rank passes the maxima of ITS views, f32[NL, n_local, 3] (NULL when it holds
+ * none), and receives all of them in pose-table order, f32[NL, n_total, 3], on the context's stream: pack, ONE ncclAllGather
+ * over `nccl_comm` (an ncclComm_t of the caller's RCCL, whose device is this context's), unpack.  RCCL is looked up at first
+ * use (MVLM_RCCL_LIB = path, else the RCCL already loaded in the process, else librccl.so.1): nothing links against it.
+ * nccl_comm == NULL is allowed in a world of one.  The Python host uses torch.distributed instead (same layout). */
+int mvlm_allgather_maxima(mvlm_ctx* ctx, void* nccl_comm, int rank, int world, const float* maxima_local_dev, int n_total,
+                          int n_landmarks, float* maxima_all_dev);
+/* The two halves around the transport, for a host that moves the slots itself (MPI, hipMemcpyPeerAsync): a rank's slot is
+ * f32[n_max, NL, 3], n_max = ceil(n_total / world), short shards zero-padded; slots_dev = the `world` slots in rank order. */
+int mvlm_gather_pack(mvlm_ctx* ctx, const float* maxima_local_dev, int n_local, int n_max, int n_landmarks, float* slot_dev);
+int mvlm_gather_unpack(mvlm_ctx* ctx, const float* slots_dev, int world, int n_total, int n_landmarks, float* maxima_all_dev);
+
 #ifdef __cplusplus
 }
 #endif

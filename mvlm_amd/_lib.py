@@ -52,6 +52,9 @@ SIGNATURES = {
     "mvlm_render_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_render_get_profile": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, C.c_int]),
     "mvlm_render_rotations_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mvlm_gather_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mvlm_gather_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mvlm_allgather_maxima": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mvlm_set_render_shading": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_set_render_subpixel_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "mvlm_cnn_load": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_int32_p, C.c_int, C.c_int, C.c_int]),

@@ -76,3 +76,88 @@ def test_fused_step_equals_the_slot_protocol_after_the_reordering(tmp_path):
         slots = pipe.estimator_3d.project_landmarks_to_surface(mesh, raw)
         np.testing.assert_array_equal(fused, slots)
         assert err == err2
+
+
+# ---- the sharded path's exchange through the C ABI (mvlm_allgather_maxima) ------------------------------------------------
+def _gather(ctx, comm, rank, world, local, n_total, nl):
+    import ctypes as C
+
+    out = torch.full((nl, n_total, 3), -7.0, dtype=torch.float32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rc = ctx.lib.mvlm_allgather_maxima(ctx.handle, comm, rank, world, C.c_void_p(local.data_ptr()) if local is not None else None,
+                                       n_total, nl, C.c_void_p(out.data_ptr()))
+    return rc, out
+
+
+def test_allgather_maxima_world_of_one_without_a_communicator():
+    from mvlm_amd import _lib
+
+    ctx = _lib.get_context(0)
+    rs = np.random.RandomState(3)
+    for nl, n in ((73, 12), (478, 128), (84, 1)):
+        local = torch.from_numpy(rs.standard_normal((nl, n, 3)).astype(np.float32)).cuda()
+        rc, out = _gather(ctx, None, 0, 1, local, n, nl)
+        assert rc == 0 and torch.equal(out, local)
+    rc, _ = _gather(ctx, None, 0, 2, local, 2, 84)      # more than one rank needs a communicator
+    assert rc != 0 and b"communicator" in ctx.lib.mvlm_last_error(ctx.handle)
+
+
+@pytest.mark.parametrize("n_total,nl,world", [(96, 73, 8), (128, 478, 8), (100, 84, 8), (5, 73, 8), (96, 84, 2), (7, 84, 3)])
+def test_gather_pack_and_unpack_for_every_rank_of_a_world(n_total, nl, world):
+    """The layout of the exchange with EVERY rank played on this GPU: each rank's shard packed into its slot, the slots unpacked
+    = the full tensor in view order - even, uneven and more-ranks-than-views splits; the same answer as the Python host's
+    torch.distributed path (mvlm_amd/parallel.py all_gather_views, whose shard_range this follows)."""
+    import ctypes as C
+
+    from mvlm_amd import _lib, parallel
+
+    ctx = _lib.get_context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rs = np.random.RandomState(n_total + world)
+    full = torch.from_numpy(rs.standard_normal((nl, n_total, 3)).astype(np.float32)).cuda()
+    n_max = -(-n_total // world)
+    slots = torch.full((world, n_max, nl, 3), 9.0, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        lo, hi = parallel.shard_range(n_total, r, world)
+        local = full[:, lo:hi].contiguous()
+        assert ctx.lib.mvlm_gather_pack(ctx.handle, C.c_void_p(local.data_ptr()) if hi > lo else None, hi - lo, n_max, nl,
+                                        C.c_void_p(slots[r].data_ptr())) == 0
+        assert torch.equal(slots[r, :hi - lo], local.permute(1, 0, 2)) and not slots[r, hi - lo:].any()
+    out = torch.empty_like(full)
+    assert ctx.lib.mvlm_gather_unpack(ctx.handle, C.c_void_p(slots.data_ptr()), world, n_total, nl, C.c_void_p(out.data_ptr())) == 0
+    assert torch.equal(out, full)
+
+
+def test_allgather_maxima_over_rccl_in_a_world_of_one():
+    """A real ncclComm_t (RCCL's own library through ctypes, one rank on this GPU) handed to the C entry point: pack,
+    ncclAllGather on the context's stream, unpack = the identity on this rank's views."""
+    import ctypes as C
+    import os
+
+    from mvlm_amd import _lib
+
+    path = os.environ.get("MVLM_RCCL_LIB", "/opt/rocm/lib/librccl.so.1")
+    if not os.path.exists(path):
+        pytest.skip("no RCCL library")
+    os.environ["MVLM_RCCL_LIB"] = path       # the library the communicator comes from is the one the entry point must call
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        ctx = _lib.get_context(0)
+        rs = np.random.RandomState(5)
+        local = torch.from_numpy(rs.standard_normal((84, 96, 3)).astype(np.float32)).cuda()
+        rc, out = _gather(ctx, comm, 0, 1, local, 96, 84)
+        assert rc == 0, ctx.lib.mvlm_last_error(ctx.handle)
+        torch.cuda.synchronize()
+        assert torch.equal(out, local)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

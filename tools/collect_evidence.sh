@@ -18,7 +18,7 @@ export MVLM_BENCH_NO_INGEST=1 MVLM_BENCH_LIVE_TRAFFIC=0
 echo "== other configs" ; date
 timeout -k 10 300 python3 bench.py --config bu3dfe-depth-8 --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_b8views.json 2> $OUT/${TAG}_bench_b8views.stderr.txt || exit 1
 timeout -k 10 300 python3 bench.py --config dtu3d-rgb-64 --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_dtu3d_rgb_64views.json 2> /dev/null || exit 1
-timeout -k 10 300 python3 bench.py --config mediapipe-478x128 --steps 20 --warmup 5 --cpu-views 0 > $OUT/${TAG}_bench_mediapipe_478x128.json 2> /dev/null || exit 1
+timeout -k 10 300 python3 bench.py --config mediapipe-478x128 --steps 200 --warmup 5 --cpu-views 0 > $OUT/${TAG}_bench_mediapipe_478x128.json 2> /dev/null || exit 1
 echo "== one GPU's share of the headline configuration at N = 2 / 4 / 8 (48 / 24 / 12 of the 96 views)" ; date
 for v in 48 24 12; do
   timeout -k 10 300 python3 bench.py --views-total $v --steps 20 --warmup 5 --cpu-views 0 --no-fast-mode > $OUT/${TAG}_bench_bu3dfe_rgbd_${v}views.json 2> /dev/null || exit 1
