@@ -1,6 +1,6 @@
 """The renderer contract (what oracle/raster.c and csrc/raster.hip both implement) against a real OpenGL.
 
-tests/golden/gl_raster.npz = the reference's GL work for ten scenes, drawn by SwiftShader's OpenGL ES 3.0 and post-processed
+tests/golden/gl_raster.npz = the reference's GL work for eleven scenes, drawn by SwiftShader's OpenGL ES 3.0 and post-processed
 with the reference's own read-back code (tools/make_gl_golden.py, tools/gl_reference.py).  This file holds the CPU oracle
 against it; tests/test_gpu_gl_contract.py does the same for the HIP rasteriser.  tests/gl_contract.py explains the classes a
 disagreement may fall into.  The numbers asserted are the measured ones: a change of the contract that moves them shows here."""
@@ -14,7 +14,7 @@ GL_BITS = META["gl"]["subpixel_bits"]
 
 # measured with oracle/raster.c at the GL's own sub-pixel precision: {scene: (clip, texel, depth1)} upper bounds
 MEASURED = {
-    "face40": (0, 2, 2), "coarse": (0, 21, 1), "centres": (0, 0, 0), "uv_wrap": (8, 5, 0), "last_texel": (0, 0, 0),
+    "face40": (0, 2, 2), "face224": (0, 9, 1), "coarse": (0, 21, 1), "centres": (0, 0, 0), "uv_wrap": (8, 5, 0), "last_texel": (0, 0, 0),
     "coplanar": (0, 0, 0), "clip": (0, 0, 0), "offscreen": (5, 20, 1), "third": (0, 0, 36864), "depth_ramp": (0, 0, 0),
 }
 
@@ -55,8 +55,9 @@ def test_lattice_scenes_do_not_depend_on_the_subpixel_bits(name):
 
 def test_the_subpixel_bits_are_the_only_thing_between_the_default_contract_and_this_gl():
     """At 8 bits (GPUs) the same scenes differ from the 4-bit GL on a fraction of a percent of the pixels - silhouettes moved
-    by < 1/16 pixel and texels next to a boundary; at the GL's own 4 bits they do not (test above).  Bounds = measured."""
-    measured = {"face40": 0.0040, "coarse": 0.0020, "uv_wrap": 0.0010, "offscreen": 0.0020}
+    by < 1/16 pixel and texels next to a boundary (most on the 224-grid face, whose triangles are smaller than a pixel and whose
+    texture has 1.5 texels per pixel: 1.3 %); at the GL's own 4 bits they do not (test above).  Bounds = measured."""
+    measured = {"face40": 0.0040, "face224": 0.0150, "coarse": 0.0020, "uv_wrap": 0.0010, "offscreen": 0.0020}
     for name, bound in measured.items():
         sc = SCENES[name]
         got = np.round(_oracle(sc, 8) * 255.0).astype(np.uint8)

@@ -32,6 +32,7 @@ timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 96 224 bu3dfe fast1
 timeout -k 10 900 python3 tests/reports/e2e_parity_report.py 64 224 dtu3d fast16 RGB > $OUT/${TAG}_fast16_vs_oracle_dtu3d_rgb_64views.txt 2>&1 || exit 1
 echo "== the renderer contract against a real OpenGL's rendering (tests/golden/gl_raster.npz), the reference's own textures" ; date
 timeout -k 10 300 python3 tests/reports/gl_contract_report.py > $OUT/${TAG}_gl_contract.txt 2>&1 || exit 1
+timeout -k 10 300 python3 tests/reports/gl_sensitivity_report.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_gl_sensitivity.txt || exit 1
 timeout -k 10 300 python3 -m pytest tests/test_real_textures.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep "synchronisation rounds\|passed\|failed" > $OUT/${TAG}_real_textures.txt || exit 1
 echo "== moment selection (fused) beside simple" ; date
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-views 0 --no-fast-mode --selection moment > $OUT/${TAG}_bench_moment_96views.json 2> /dev/null || exit 1

@@ -77,6 +77,10 @@ def scenes():
     # 1. the 40-grid face, fixed 8-view table: sub-pixel-free triangles of ~4 px, silhouettes, self-occlusion at +-45 deg
     m = face_like_mesh(grid=40, tex_size=64, seed=1)
     out["face40"] = dict(verts=m.verts, tris=m.tris, uvs=m.uvs, tex=m.texture, poses=EIGHT_VIEWS, lattice=False)
+    # 1b. the bench's own regime: the 224-grid face (99 458 triangles, most of them smaller than a pixel), three poses
+    m = face_like_mesh(grid=224, tex_size=256, seed=0)
+    out["face224"] = dict(verts=m.verts, tris=m.tris, uvs=m.uvs, tex=m.texture,
+                          poses=np.array([[30, 15, 0], [-30, -45, 0], [-17, 33, 9]], np.float64), lattice=False)
     # 2. a coarse mesh: 3x3 vertices over +-120 -> triangles of ~100 px (the rasteriser's "big triangle" path), odd-sized texture
     lin = np.linspace(-120.0, 120.0, 3)
     x, y = np.meshgrid(lin, lin)
