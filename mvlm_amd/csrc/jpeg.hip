@@ -571,5 +571,13 @@ int mvlm_jpeg_run(mvlm_ctx* ctx, MvlmJpegPlan& plan, const uint8_t* stage_pinned
     // 0 and 2 return with the stream drained (see above).  A HIP failure may leave copies and kernels queued that still read the
     // staging slot and write rgb_dev, and the callers hand both back to their pools next: wait here, whatever the wait returns.
     if (rc == 1) (void)hipStreamSynchronize(stream);
+    // The scratch is grow-only for the textures a scanner writes (~50 MB at 3546 x 2282); one oversized file (the parser admits up
+    // to 16384 x 16384 = 2.6 GB of scratch) does not keep its allocation for the life of the context.
+    if (ctx->jpeg_scratch && ctx->jpeg_scratch_cap > (size_t(512) << 20)) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(ctx->jpeg_scratch);
+        ctx->jpeg_scratch = nullptr;
+        ctx->jpeg_scratch_cap = 0;
+    }
     return rc;
 }
