@@ -474,6 +474,9 @@ def main():
         # started as a plain process: the N ranks are this process's children; it never touches the GPU itself
         sys.exit(launch_ranks(args.gpus))
 
+    # a rank started by an external launcher (the driver's torch.distributed.run) may not have inherited the image's environment:
+    # dmabuf IPC for RCCL must be chosen before this process first touches the GPU (mvlm_amd/parallel.py rccl_environment)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
