@@ -161,3 +161,26 @@ def test_allgather_maxima_over_rccl_in_a_world_of_one():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_render_overflow_is_reported_and_the_next_render_is_clean():
+    """A mesh of window-filling triangles overflows the per-view tile lists (4 T + 16 384 entries: 100 triangles x 256 tiles):
+    mvlm_render_check says so - the flag now reaches the host inside the tile kernel - and the render after it is bit-equal to
+    the oracle again (counters, key plane and flag all start clean)."""
+    from mvlm_amd import _lib
+    from mvlm_amd.utils import HipRenderer3D, Mesh
+    from oracle import raster
+
+    n = 100
+    rs = np.random.RandomState(2)
+    verts = np.concatenate([np.array([[-400, -400, z], [400, -400, z], [0, 600, z]], np.float32) for z in rs.uniform(-50, 50, n)])
+    huge = Mesh(verts, np.arange(3 * n, dtype=np.int32).reshape(n, 3))
+    r = HipRenderer3D(n_views=8, verbose=False)
+    poses = r.generate_3d_transformations()
+    r.render_device(huge, poses)
+    with pytest.raises(_lib.MvlmHipError, match="overflowed"):
+        r.check()
+    face = _face(40)
+    got = r.render_device(face, poses).cpu().numpy()
+    r.check()
+    np.testing.assert_array_equal(got, raster.multiview_render(face.verts, face.tris, face.uvs, face.texture, poses))
