@@ -10,7 +10,7 @@
  * tools/make_gl_golden.py -> tests/golden/gl_raster.npz) and this file is held against that
  * (tests/test_gl_contract.py): fill rule, pixel centres, depth mapping and byte conversion,
  * LEQUAL, clip planes, texel addressing and flip below are the ones that GL shows; what GL
- * leaves to the implementation (sub-pixel bits, guard band) is listed in DESIGN.md section 5:
+ * leaves to the implementation (sub-pixel bits, guard band) is listed in DESIGN.md section 5.1:
  *   - per pose M = Ry*Rx*Rz (render3d.py:140-144) applied in double, points kept
  *     as float (vtkTransformPolyDataFilter on float points),
  *   - orthographic camera at z=+500 looking down -z, parallel scale 150, 256x256

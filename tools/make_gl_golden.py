@@ -9,7 +9,7 @@ post-processing literally (gl_reference.reference_postprocess) and stores inputs
   * tests/test_gpu_gl_contract.py (-m gpu) holds the HIP rasteriser against them.
 What this pins: pixel centres, fill rule, window mapping, depth mapping and byte conversion, LEQUAL in draw order, near/far
 clipping, texel addressing (NEAREST, REPEAT, bottom-up rows), row flip.  What it cannot pin: choices OpenGL leaves to the
-implementation and that differ between this one and the GPU a user's VTK would run on - listed in DESIGN.md section 5.
+implementation and that differ between this one and the GPU a user's VTK would run on - listed in DESIGN.md section 5.1.
 
     python tools/make_gl_golden.py [--out tests/golden/gl_raster.npz]
 """
